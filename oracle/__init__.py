@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes front-end of the plain-C CPU oracle.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package; the product in ``marl_amd/`` never does.  The algorithm
+restated here is documented in ``overcooked_oracle.h`` (reference citations and
+parity status live there).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+FEATURE_IDS = {
+    "global_obs": 0,
+    "local_obs": 1,
+    "Minimal_spatial": 2,
+    "Minimal_spatial_other_agent_aware": 3,
+    "only_direction": 4,
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so next to its source (gcc, seconds)."""
+    src = os.path.join(_HERE, "overcooked_oracle.c")
+    hdr = os.path.join(_HERE, "overcooked_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class _Layout(ctypes.Structure):
+    _fields_ = [
+        ("H", ctypes.c_int), ("W", ctypes.c_int), ("A", ctypes.c_int),
+        ("max_steps", ctypes.c_int), ("feature", ctypes.c_int), ("dist_metric", ctypes.c_int),
+        ("type", ctypes.c_ubyte * 256),
+        ("nspawn", ctypes.c_int), ("spawn", ctypes.c_int * 256),
+        ("npots", ctypes.c_int), ("pot_cell", ctypes.c_int * 8),
+        ("obs_dim", ctypes.c_int), ("block_dim", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp = ctypes.c_void_p
+        L.oc_layout_init.restype = ctypes.c_int
+        L.oc_layout_init.argtypes = [ctypes.POINTER(_Layout), ctypes.POINTER(ctypes.c_char_p), ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.oc_reset_batch.restype = None
+        L.oc_reset_batch.argtypes = [ctypes.POINTER(_Layout), ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                     vp, vp, vp, vp, vp, vp, vp, ctypes.c_int]
+        L.oc_step_batch.restype = None
+        L.oc_step_batch.argtypes = [ctypes.POINTER(_Layout), ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                    vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int]
+        L.oc_featurize_batch.restype = None
+        L.oc_featurize_batch.argtypes = [ctypes.POINTER(_Layout), ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int]
+        L.oc_gae.restype = None
+        L.oc_gae.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                             vp, vp, ctypes.c_int]
+        L.oc_rng_u32.restype = ctypes.c_uint32
+        L.oc_rng_u32.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleVecEnv:
+    """E independent Overcooked envs stepped on the CPU, canonical-snapshot state in numpy."""
+
+    def __init__(self, layout_rows, num_agents, feature="global_obs", max_steps=1000, num_envs=1,
+                 seed=0, env_index_base=0, dist_metric=0, nthreads=1):
+        self._lib = lib()
+        self.layout = _Layout()
+        rows = (ctypes.c_char_p * len(layout_rows))(*[r.encode() for r in layout_rows])
+        feat = FEATURE_IDS[feature] if isinstance(feature, str) else int(feature)
+        rc = self._lib.oc_layout_init(ctypes.byref(self.layout), rows, len(layout_rows), num_agents, feat,
+                                      max_steps, dist_metric)
+        if rc != 0:
+            raise ValueError(f"oc_layout_init failed with {rc}")
+        self.E, self.A = int(num_envs), int(num_agents)
+        self.H, self.W = self.layout.H, self.layout.W
+        self.NP = self.layout.npots
+        self.D = self.layout.obs_dim
+        self.seed, self.env_index_base = int(seed), int(env_index_base)
+        self.nthreads = int(nthreads)
+        self.agents = np.zeros((self.E, self.A, 4), np.int32)
+        self.pots = np.zeros((self.E, max(self.NP, 1), 2), np.int32)[:, : self.NP].copy()
+        self.items = np.zeros((self.E, self.H * self.W), np.uint8)
+        self.misc = np.zeros((self.E, 2), np.int32)
+
+    # -- state snapshot helpers -------------------------------------------------
+    def snapshot(self):
+        return {"agents": self.agents.copy(), "pots": self.pots.copy(), "items": self.items.copy(),
+                "misc": self.misc.copy()}
+
+    def load_snapshot(self, snap):
+        self.agents[...] = snap["agents"]
+        self.pots[...] = snap["pots"]
+        self.items[...] = snap["items"]
+        self.misc[...] = snap["misc"]
+
+    # -- env API -----------------------------------------------------------------
+    def reset(self, spawn_override=None, dir_override=None):
+        obs = np.empty((self.E * self.A, self.D), np.float32)
+        so = None if spawn_override is None else np.ascontiguousarray(spawn_override, np.uint8)
+        do = None if dir_override is None else np.ascontiguousarray(dir_override, np.uint8)
+        self._lib.oc_reset_batch(ctypes.byref(self.layout), self.E, self.seed, self.env_index_base,
+                                 _p(self.agents), _p(self.pots), _p(self.items), _p(self.misc),
+                                 _p(so), _p(do), _p(obs), self.nthreads)
+        return obs
+
+    def step(self, actions, prio_override=None, want_obs=True):
+        actions = np.ascontiguousarray(actions, np.int64).reshape(self.E * self.A)
+        obs = np.empty((self.E * self.A, self.D), np.float32) if want_obs else None
+        rew = np.empty(self.E * self.A, np.float32)
+        term = np.empty(self.E * self.A, np.uint8)
+        trunc = np.empty(self.E * self.A, np.uint8)
+        po = None if prio_override is None else np.ascontiguousarray(prio_override, np.uint8)
+        self._lib.oc_step_batch(ctypes.byref(self.layout), self.E, self.seed, self.env_index_base,
+                                _p(self.agents), _p(self.pots), _p(self.items), _p(self.misc),
+                                _p(actions), _p(po), _p(obs), _p(rew), _p(term), _p(trunc), self.nthreads)
+        return obs, rew, term.astype(bool), trunc.astype(bool)
+
+    def featurize(self):
+        obs = np.empty((self.E * self.A, self.D), np.float32)
+        self._lib.oc_featurize_batch(ctypes.byref(self.layout), self.E, _p(self.agents), _p(self.pots),
+                                     _p(self.items), _p(self.misc), _p(obs), self.nthreads)
+        return obs
+
+
+def gae(rewards, dones, values, next_values, gamma=0.99, lam=0.95, mode=0):
+    """Returns (advantages, value_targets), float32 [T, N]."""
+    rewards = np.ascontiguousarray(rewards, np.float32)
+    dones = np.ascontiguousarray(dones, np.float32)
+    values = np.ascontiguousarray(values, np.float32)
+    next_values = np.ascontiguousarray(next_values, np.float32).reshape(-1)
+    T, N = rewards.shape
+    assert next_values.size == (1 if mode == 1 else N)
+    adv = np.empty((T, N), np.float32)
+    ret = np.empty((T, N), np.float32)
+    lib().oc_gae(_p(rewards), _p(dones), _p(values), _p(next_values), T, N, gamma, lam, _p(adv), _p(ret), mode)
+    return adv, ret
+
+
+def rng_u32(seed, env_index, counter):
+    return int(lib().oc_rng_u32(seed, env_index, counter))
