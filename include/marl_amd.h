@@ -1,0 +1,130 @@
+/*
+ * marl_amd.h -- C ABI of libmarl_amd.so: batched Overcooked step / reset / featurize and the
+ * GAE pass for MI355X (gfx950).
+ *
+ * The reference (loganwoudstra/MARL) is pure Python and has no FFI of its own; the boundary
+ * it does have is the duck-typed vector env returned by main.py:66-96 `make_vector_env`
+ * and driven at agent_environment.py:34,50,88, plus `compute_gae`
+ * (agents/MAPPO.py:82-114, agents/CentralizedMAPPO.py:48-82).  Each entry point below names
+ * the reference call it stands behind.  All pointers named d_* are DEVICE pointers owned by
+ * the caller (16-byte aligned where noted); `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  Nothing here synchronises the device or allocates in the
+ * per-step calls; marl_env_create / marl_env_destroy allocate and free the small per-layout
+ * lookup tables.  Every function returns 0 on success and a negative code on failure;
+ * marl_last_error() describes the last failure on the calling thread.
+ */
+#ifndef MARL_AMD_H
+#define MARL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct marl_env marl_env_t;
+
+/* feature sets: names registered at overcooked_config.py:14-28 (+ README.md:65) */
+enum {
+    MARL_FEAT_GLOBAL_OBS = 0,             /* "global_obs"   overcooked_features.py:11-130 */
+    MARL_FEAT_LOCAL_OBS = 1,              /* "local_obs"    overcooked_features.py:132-229 */
+    MARL_FEAT_MINIMAL_SPATIAL = 2,        /* "Minimal_spatial" :284-312 */
+    MARL_FEAT_MINIMAL_SPATIAL_OTHER = 3,  /* "Minimal_spatial_other_agent_aware" :231-281 */
+    MARL_FEAT_ONLY_DIRECTION = 4          /* "only_direction" README.md:65,112 */
+};
+
+enum {
+    MARL_OK = 0,
+    MARL_ERR_INVALID = -1,   /* bad argument (shape, alignment, unsupported agent count ...) */
+    MARL_ERR_LAYOUT = -2,    /* malformed ASCII layout */
+    MARL_ERR_HIP = -3        /* a HIP runtime call failed */
+};
+
+const char *marl_last_error(void);
+
+/*
+ * Build an env family on the current HIP device.
+ * Stands behind main.py:29-64 `make_env` + main.py:66-96 `make_vector_env`:
+ *   layout_rows/height  the ASCII grid (overcooked_config.py:34-62 legend; '+' = spawn floor)
+ *   num_agents          1, 2 or 4 (config["num_agents"], main.py:48)
+ *   feature             MARL_FEAT_* (config["features"], main.py:50)
+ *   max_steps           episode length before truncation (overcooked_config.py:108)
+ *   num_envs            E, envs held by THIS process (rows = E * num_agents, env-major)
+ *   seed, env_index_base  counter-RNG key: env e draws from (seed, env_index_base + e), so
+ *                       a shard of a larger job reproduces the same envs as the whole job
+ *   dist_metric         0 = L1, 1 = squared L2 ordering for the "closest" features
+ */
+int marl_env_create(marl_env_t **out, const char *const *layout_rows, int height, int num_agents,
+                    int feature, int max_steps, int num_envs, uint64_t seed, int64_t env_index_base,
+                    int dist_metric);
+void marl_env_destroy(marl_env_t *env);
+
+/* shape queries */
+int marl_env_obs_dim(const marl_env_t *env);       /* D: single_observation_space.shape[0], main.py:92 */
+int marl_env_num_rows(const marl_env_t *env);      /* E * A: vec_env.num_envs, main.py:186 */
+int marl_env_num_pots(const marl_env_t *env);
+int marl_env_grid_cells(const marl_env_t *env);    /* H * W */
+int marl_env_state_words(const marl_env_t *env);   /* uint32 words per env of packed state */
+size_t marl_env_state_bytes(const marl_env_t *env);/* bytes the caller must allocate for d_state */
+
+/*
+ * vec_env.reset() (agent_environment.py:34,88): every env restarts; d_obs receives
+ * float32 [E*A][D] (16-byte aligned).  d_spawn_override / d_dir_override: uint8 [E][A]
+ * (cell index row*W+col / direction 0-3) or NULL to draw from the counter RNG.
+ * d_state must have been zero-filled before the first reset (the RNG draw counter lives
+ * in it and survives resets).
+ */
+int marl_env_reset(marl_env_t *env, void *d_state, float *d_obs, const uint8_t *d_spawn_override,
+                   const uint8_t *d_dir_override, void *stream);
+
+/*
+ * vec_env.step(actions) (agent_environment.py:50): d_actions holds E*A action indices in
+ * [0,7) with element size action_elem_size in {1, 4, 8} bytes (8 = the int64 that
+ * `actions.cpu().numpy()` yields).  Outputs: d_obs float32 [E*A][D] (16-byte aligned),
+ * d_rewards float32 [E*A], d_terminated / d_truncated uint8 [E*A].  An env whose agents are
+ * all done restarts inside the call and reports the new episode's first observation
+ * together with the done flags.  d_prio_override: uint8 [E][A] rank per agent (lower moves
+ * first) replacing the RNG shuffle of movers, or NULL.
+ */
+int marl_env_step(marl_env_t *env, void *d_state, const void *d_actions, int action_elem_size,
+                  float *d_obs, float *d_rewards, uint8_t *d_terminated, uint8_t *d_truncated,
+                  const uint8_t *d_prio_override, void *stream);
+
+/* feature_space.generate over the stored state (overcooked_features.py:107-121) */
+int marl_env_featurize(marl_env_t *env, void *d_state, float *d_obs, void *stream);
+
+/*
+ * Canonical snapshot <-> packed state, for parity harnesses and state injection:
+ *   d_agents int32 [E][A][4] = (row, col, dir, inv)      inv: 0 none 1 onion 2 plate 3 soup
+ *   d_pots   int32 [E][NP][2] = (onion count, cooking timer)
+ *   d_items  uint8 [E][H*W]  item lying on each floor / counter cell
+ *   d_misc   int32 [E][2]    = (t, RNG draw counter)
+ */
+int marl_env_export_state(marl_env_t *env, const void *d_state, int32_t *d_agents, int32_t *d_pots,
+                          uint8_t *d_items, int32_t *d_misc, void *stream);
+int marl_env_import_state(marl_env_t *env, void *d_state, const int32_t *d_agents, const int32_t *d_pots,
+                          const uint8_t *d_items, const int32_t *d_misc, void *stream);
+
+/*
+ * compute_gae + value targets.
+ * mode 0: agents/MAPPO.py:82-114 and :144.  d_next_values float32 [N].
+ * mode 1: agents/CentralizedMAPPO.py:48-82: the reward of step t is the mean over all N
+ *         rows; d_next_values float32 [1].  d_reward_mean float32 [T] is workspace: when
+ *         reward_mean_ready == 0 the call fills it from d_rewards first; a multi-GPU caller
+ *         all-reduces its own means and passes reward_mean_ready == 1.
+ * d_rewards, d_dones, d_values, d_adv, d_ret: float32 [T][N] (row t contiguous).
+ * d_ret may be NULL.  Arithmetic is float32 with every product and sum rounded
+ * separately, in the reference's evaluation order.
+ */
+int marl_gae(const float *d_rewards, const float *d_dones, const float *d_values,
+             const float *d_next_values, int T, int N, double gamma, double lam, float *d_adv,
+             float *d_ret, int mode, float *d_reward_mean, int reward_mean_ready, void *stream);
+
+/* per-step reward sums over rows, double [T]; lets a sharded caller form the global mean */
+int marl_row_sums(const float *d_x, int T, int N, double *d_sums, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,398 @@
+// Host side of libmarl_amd.so: the extern "C" entry points of include/marl_amd.h, the
+// per-layout lookup-table builder, and the small pack/unpack kernels behind
+// marl_env_export_state / marl_env_import_state.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/marl_amd.h"
+#include "oc_common.h"
+
+namespace oc {
+template <int A>
+hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint8_t* tab, uint32_t* state,
+                               const void* actions, int act_size, const uint8_t* prio, const uint8_t* spawn_ov,
+                               const uint8_t* dir_ov, float* obs, float* rewards, uint8_t* term, uint8_t* trunc,
+                               int mode, hipStream_t stream);
+extern template hipError_t launch_env_kernel_A<1>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+                                                  const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
+                                                  uint8_t*, int, hipStream_t);
+extern template hipError_t launch_env_kernel_A<2>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+                                                  const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
+                                                  uint8_t*, int, hipStream_t);
+extern template hipError_t launch_env_kernel_A<4>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+                                                  const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
+                                                  uint8_t*, int, hipStream_t);
+hipError_t launch_gae(const float* rewards, const float* dones, const float* values, const float* next_values,
+                      int T, int N, float gamma, float gl, float* adv, float* ret, int mode, const float* rmean,
+                      hipStream_t stream);
+hipError_t launch_row_sums(const float* x, int T, int N, double* sums, float* mean_out, hipStream_t stream);
+}  // namespace oc
+
+using namespace oc;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+static int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return MARL_ERR_HIP;
+}
+
+struct marl_env {
+    EnvParams P;
+    int A, feat, niw, H, W, ncell, NP, D, BLK, words;
+    std::vector<uint8_t> tab;  // host copy of the lookup blob
+    uint8_t* d_tab;
+};
+
+// ---------------------------------------------------------------------------------------
+// lookup tables
+// ---------------------------------------------------------------------------------------
+static uint32_t mix32_host(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+static int dist_of(int metric, int dy, int dx) {
+    return metric ? dy * dy + dx * dx : std::abs(dy) + std::abs(dx);
+}
+
+// (agent - object) for the n nearest cells of one static type; stable on ties => scan order
+static void static_closest(const std::vector<uint8_t>& type, int W, int ncell, uint32_t kind, int n, int ar, int ac,
+                           int metric, int8_t* out) {
+    std::vector<std::pair<int, int>> cand;  // (distance, cell)
+    for (int c = 0; c < ncell; ++c)
+        if (type[c] == kind) cand.push_back({dist_of(metric, ar - c / W, ac - c % W), c});
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    for (int k = 0; k < n && k < (int)cand.size(); ++k) {
+        out[2 * k] = (int8_t)(ar - cand[k].second / W);
+        out[2 * k + 1] = (int8_t)(ac - cand[k].second % W);
+    }
+}
+
+static int build_tables(marl_env* env, const char* const* rows, int height, int dist_metric) {
+    const int H = height;
+    if (H <= 0 || rows == nullptr || rows[0] == nullptr) return fail(MARL_ERR_LAYOUT, "layout has no rows");
+    const int W = (int)strlen(rows[0]);
+    if (W < 3 || H < 3) return fail(MARL_ERR_LAYOUT, "layout smaller than 3x3");
+    if (H * W > MAX_CELLS) return fail(MARL_ERR_LAYOUT, "layout has more than 256 cells");
+    const int ncell = H * W;
+    std::vector<uint8_t> type(ncell, WALL);
+    std::vector<int> spawn, floor_cells, pot_cells, slots;
+    for (int r = 0; r < H; ++r) {
+        if (rows[r] == nullptr || (int)strlen(rows[r]) != W) return fail(MARL_ERR_LAYOUT, "layout rows differ in width");
+        for (int c = 0; c < W; ++c) {
+            const int cell = r * W + c;
+            const bool border = (r == 0 || c == 0 || r == H - 1 || c == W - 1);
+            switch (rows[r][c]) {
+                case '#': type[cell] = WALL; break;
+                case ' ': type[cell] = FLOOR; break;
+                case '+': type[cell] = FLOOR; spawn.push_back(cell); break;
+                case 'C': type[cell] = COUNTER; break;
+                case 'U': type[cell] = POT; pot_cells.push_back(cell); break;
+                case 'O': type[cell] = ONION_STACK; break;
+                case '=': type[cell] = PLATE_STACK; break;
+                case '@': type[cell] = DELIVERY; break;
+                default: return fail(MARL_ERR_LAYOUT, std::string("unknown layout character '") + rows[r][c] + "'");
+            }
+            if (border && type[cell] == FLOOR) return fail(MARL_ERR_LAYOUT, "floor on the border: the grid must be enclosed");
+            if (type[cell] == FLOOR) floor_cells.push_back(cell);
+            if (type[cell] == FLOOR || type[cell] == COUNTER) slots.push_back(cell);
+        }
+    }
+    const int A = env->A;
+    if ((int)pot_cells.size() > MAX_POTS) return fail(MARL_ERR_LAYOUT, "more than 8 pots");
+    if ((int)floor_cells.size() < A) return fail(MARL_ERR_LAYOUT, "fewer floor cells than agents");
+    if (!spawn.empty() && (int)spawn.size() < A) return fail(MARL_ERR_LAYOUT, "fewer '+' spawn cells than agents");
+    if ((int)slots.size() > 128) return fail(MARL_ERR_LAYOUT, "more than 128 item-capable cells");
+
+    env->H = H; env->W = W; env->ncell = ncell; env->NP = (int)pot_cells.size();
+    env->BLK = block_dim(A, env->feat);
+    env->D = env->feat == FEAT_GLOBAL ? A * env->BLK : env->BLK;
+    const int NW = (env->BLK + 3) / 4;
+    env->niw = item_words_padded((int)slots.size());
+    env->words = state_words(A, env->NP, (int)slots.size());
+
+    const int nfloor = (int)floor_cells.size();
+    size_t bytes = TAB_POSTAB + (size_t)nfloor * NW * 4;
+    bytes = (bytes + 15) & ~(size_t)15;
+    env->tab.assign(bytes, 0);
+    uint8_t* t = env->tab.data();
+    memset(t + TAB_SLOT_OF_CELL, 0xFF, 256);
+    memset(t + TAB_POT_OF_CELL, 0xFF, 256);
+    memset(t + TAB_FIDX_OF_CELL, 0, 256);
+    memset(t + TAB_POT_ORDER, 0xFF, 512);
+    for (int c = 0; c < ncell; ++c) {
+        t[TAB_CELLTYPE + c] = type[c];
+        reinterpret_cast<uint16_t*>(t + TAB_CELL_RC)[c] = (uint16_t)(((c / W) << 8) | (c % W));
+    }
+    for (int k = 0; k < (int)slots.size(); ++k) { t[TAB_SLOT_OF_CELL + slots[k]] = (uint8_t)k; t[TAB_CELL_OF_SLOT + k] = (uint8_t)slots[k]; }
+    for (int k = 0; k < (int)pot_cells.size(); ++k) { t[TAB_POT_OF_CELL + pot_cells[k]] = (uint8_t)k; t[TAB_POT_CELL + k] = (uint8_t)pot_cells[k]; }
+    for (int k = 0; k < nfloor; ++k) { t[TAB_FIDX_OF_CELL + floor_cells[k]] = (uint8_t)k; t[TAB_FLOOR_CELL + k] = (uint8_t)floor_cells[k]; }
+    for (int k = 0; k < (int)spawn.size(); ++k) t[TAB_SPAWN_CELL + k] = (uint8_t)spawn[k];
+
+    const bool full = env->feat == FEAT_GLOBAL || env->feat == FEAT_LOCAL;
+    const bool others = full || env->feat == FEAT_MINIMAL_OTHER;
+    const bool spatial = env->feat != FEAT_ONLY_DIRECTION;
+    const int o_pos = (full ? 93 : 27) + (others ? 2 * (A - 1) : 0);
+    static const int adj_dr[4] = {0, 0, 1, -1}, adj_dc[4] = {1, -1, 0, 0};  // right, left, down, up
+    for (int k = 0; k < nfloor; ++k) {
+        const int cell = floor_cells[k], ar = cell / W, ac = cell % W;
+        int8_t* blk = reinterpret_cast<int8_t*>(t + TAB_POSTAB) + (size_t)k * NW * 4;
+        // nearest pots, used by the kernel for the dynamic pot fields as well
+        std::vector<std::pair<int, int>> pots;  // (distance, pot id)
+        for (int p = 0; p < env->NP; ++p) pots.push_back({dist_of(dist_metric, ar - pot_cells[p] / W, ac - pot_cells[p] % W), p});
+        std::stable_sort(pots.begin(), pots.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+        for (int j = 0; j < 2 && j < env->NP; ++j) t[TAB_POT_ORDER + 2 * cell + j] = (uint8_t)pots[j].second;
+        if (!spatial) continue;
+        for (int j = 0; j < 4; ++j)
+            if (type[(ar + adj_dr[j]) * W + ac + adj_dc[j]] == COUNTER) blk[7 + j] = 1;
+        if (full) {
+            static_closest(type, W, ncell, PLATE_STACK, 2, ar, ac, dist_metric, blk + 43);
+            static_closest(type, W, ncell, ONION_STACK, 2, ar, ac, dist_metric, blk + 47);
+            static_closest(type, W, ncell, DELIVERY, 2, ar, ac, dist_metric, blk + 59);
+            static_closest(type, W, ncell, COUNTER, 4, ar, ac, dist_metric, blk + 63);
+            for (int j = 0; j < 2 && j < env->NP; ++j) {
+                const int pc = pot_cells[pots[j].second];
+                int8_t* q = blk + 71 + 11 * j;
+                q[0] = 1;  // "reachable", a constant in the feature this stands in for
+                q[7] = (int8_t)(ar - pc / W); q[8] = (int8_t)(ac - pc % W);
+                q[9] = (int8_t)(pc / W); q[10] = (int8_t)(pc % W);
+            }
+        }
+        blk[o_pos] = (int8_t)ar; blk[o_pos + 1] = (int8_t)ac;
+    }
+
+    EnvParams& P = env->P;
+    P.W = W; P.NP = env->NP; P.nslots = (int)slots.size(); P.nfloor = nfloor; P.nspawn = (int)spawn.size();
+    P.tab_bytes = (int)bytes; P.dist_metric = dist_metric;
+    return MARL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// snapshot kernels (one thread per env; setup / test path, not the hot path)
+// ---------------------------------------------------------------------------------------
+__global__ void export_kernel(EnvParams P, int A, int niw, int ncell, const uint8_t* __restrict__ tab,
+                              const uint32_t* __restrict__ st, int32_t* agents, int32_t* pots, uint8_t* items,
+                              int32_t* misc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E) return;
+    const size_t E = (size_t)P.E;
+    int w = 0;
+    misc[2 * e] = (int32_t)(st[(w++) * E + e] & 0xFFFFu);
+    misc[2 * e + 1] = (int32_t)st[(w++) * E + e];
+    uint64_t pw = st[(w++) * E + e];
+    if (P.NP > 4) pw |= (uint64_t)st[(w++) * E + e] << 32;
+    for (int p = 0; p < P.NP; ++p) {
+        pots[((size_t)e * P.NP + p) * 2] = (int32_t)((pw >> (8 * p)) & 3u);
+        pots[((size_t)e * P.NP + p) * 2 + 1] = (int32_t)((pw >> (8 * p + 2)) & 31u);
+    }
+    const uint16_t* rc = reinterpret_cast<const uint16_t*>(tab + TAB_CELL_RC);
+    for (int k = 0; k < (A + 1) / 2; ++k) {
+        const uint32_t aw = st[(w++) * E + e];
+        for (int h = 0; h < 2 && 2 * k + h < A; ++h) {
+            const uint32_t v = aw >> (16 * h);
+            int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
+            const uint32_t cell = v & 0xFFu;
+            o[0] = rc[cell] >> 8; o[1] = rc[cell] & 0xFF; o[2] = (v >> 8) & 3u; o[3] = (v >> 10) & 3u;
+        }
+    }
+    for (int c = 0; c < ncell; ++c) {
+        const uint32_t slot = tab[TAB_SLOT_OF_CELL + c];
+        uint8_t it = 0;
+        if (slot != 0xFFu) it = (uint8_t)((st[(size_t)(w + (slot >> 4)) * E + e] >> ((slot & 15u) * 2u)) & 3u);
+        items[(size_t)e * ncell + c] = it;
+    }
+}
+
+__global__ void import_kernel(EnvParams P, int A, int niw, int ncell, const uint8_t* __restrict__ tab, uint32_t* st,
+                              const int32_t* __restrict__ agents, const int32_t* __restrict__ pots,
+                              const uint8_t* __restrict__ items, const int32_t* __restrict__ misc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.E) return;
+    const size_t E = (size_t)P.E;
+    int w = 0;
+    st[(w++) * E + e] = (uint32_t)misc[2 * e] & 0xFFFFu;
+    st[(w++) * E + e] = (uint32_t)misc[2 * e + 1];
+    uint64_t pw = 0;
+    for (int p = 0; p < P.NP; ++p) {
+        const uint64_t b = ((uint64_t)pots[((size_t)e * P.NP + p) * 2] & 3u) |
+                           (((uint64_t)pots[((size_t)e * P.NP + p) * 2 + 1] & 31u) << 2);
+        pw |= b << (8 * p);
+    }
+    st[(w++) * E + e] = (uint32_t)pw;
+    if (P.NP > 4) st[(w++) * E + e] = (uint32_t)(pw >> 32);
+    for (int k = 0; k < (A + 1) / 2; ++k) {
+        uint32_t aw = 0;
+        for (int h = 0; h < 2 && 2 * k + h < A; ++h) {
+            const int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
+            const uint32_t v = (uint32_t)(o[0] * P.W + o[1]) | ((uint32_t)o[2] << 8) | ((uint32_t)o[3] << 10);
+            aw |= v << (16 * h);
+        }
+        st[(w++) * E + e] = aw;
+    }
+    for (int k = 0; k < niw; ++k) {
+        uint32_t word = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int slot = k * 16 + j;
+            if (slot < P.nslots) word |= ((uint32_t)items[(size_t)e * ncell + tab[TAB_CELL_OF_SLOT + slot]] & 3u) << (2 * j);
+        }
+        st[(size_t)(w + k) * E + e] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// entry points
+// ---------------------------------------------------------------------------------------
+extern "C" const char* marl_last_error(void) { return g_err.c_str(); }
+
+extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows, int height, int num_agents,
+                               int feature, int max_steps, int num_envs, uint64_t seed, int64_t env_index_base,
+                               int dist_metric) {
+    if (!out) return fail(MARL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (num_agents != 1 && num_agents != 2 && num_agents != 4)
+        return fail(MARL_ERR_INVALID, "num_agents must be 1, 2 or 4 (one lane per agent row, 64 lanes per wave)");
+    if (feature < 0 || feature > FEAT_ONLY_DIRECTION) return fail(MARL_ERR_INVALID, "unknown feature id");
+    if (max_steps <= 0 || max_steps > 65535) return fail(MARL_ERR_INVALID, "max_steps must be in [1, 65535]");
+    if (num_envs <= 0) return fail(MARL_ERR_INVALID, "num_envs must be positive");
+    if ((int64_t)num_envs * num_agents > 0x7FFFFFFF) return fail(MARL_ERR_INVALID, "num_envs * num_agents exceeds 2^31-1");
+    if (dist_metric != 0 && dist_metric != 1) return fail(MARL_ERR_INVALID, "dist_metric must be 0 or 1");
+    marl_env* env = new marl_env();
+    env->A = num_agents; env->feat = feature; env->d_tab = nullptr;
+    int rc = build_tables(env, layout_rows, height, dist_metric);
+    if (rc != MARL_OK) { delete env; return rc; }
+    EnvParams& P = env->P;
+    P.E = num_envs; P.max_steps = max_steps;
+    uint32_t k = mix32_host((uint32_t)seed + 0x9E3779B9u);
+    P.seed_key = mix32_host(k ^ (uint32_t)(seed >> 32));
+    P.env_base_lo = (uint32_t)(uint64_t)env_index_base;
+    P.env_base_hi = (uint32_t)((uint64_t)env_index_base >> 32);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&env->d_tab), env->tab.size());
+    if (e != hipSuccess) { delete env; return fail_hip(e, "hipMalloc(lookup tables)"); }
+    e = hipMemcpy(env->d_tab, env->tab.data(), env->tab.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(env->d_tab); delete env; return fail_hip(e, "hipMemcpy(lookup tables)"); }
+    *out = env;
+    return MARL_OK;
+}
+
+extern "C" void marl_env_destroy(marl_env_t* env) {
+    if (!env) return;
+    if (env->d_tab) (void)hipFree(env->d_tab);
+    delete env;
+}
+
+extern "C" int marl_env_obs_dim(const marl_env_t* env) { return env ? env->D : MARL_ERR_INVALID; }
+extern "C" int marl_env_num_rows(const marl_env_t* env) { return env ? env->P.E * env->A : MARL_ERR_INVALID; }
+extern "C" int marl_env_num_pots(const marl_env_t* env) { return env ? env->NP : MARL_ERR_INVALID; }
+extern "C" int marl_env_grid_cells(const marl_env_t* env) { return env ? env->ncell : MARL_ERR_INVALID; }
+extern "C" int marl_env_state_words(const marl_env_t* env) { return env ? env->words : MARL_ERR_INVALID; }
+extern "C" size_t marl_env_state_bytes(const marl_env_t* env) {
+    return env ? (size_t)env->words * (size_t)env->P.E * sizeof(uint32_t) : 0;
+}
+
+static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, int act_size, const uint8_t* prio,
+                          const uint8_t* spawn_ov, const uint8_t* dir_ov, float* d_obs, float* d_rewards,
+                          uint8_t* d_term, uint8_t* d_trunc, int mode, void* stream) {
+    if (!env) return fail(MARL_ERR_INVALID, "env is NULL");
+    if (!d_state) return fail(MARL_ERR_INVALID, "d_state is NULL");
+    if (!d_obs) return fail(MARL_ERR_INVALID, "d_obs is NULL");
+    if (((uintptr_t)d_obs & 15u) != 0) return fail(MARL_ERR_INVALID, "d_obs must be 16-byte aligned");
+    if (((uintptr_t)d_state & 3u) != 0) return fail(MARL_ERR_INVALID, "d_state must be 4-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    uint32_t* st = reinterpret_cast<uint32_t*>(d_state);
+    switch (env->A) {
+        case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        default: return fail(MARL_ERR_INVALID, "unsupported agent count");
+    }
+    if (e != hipSuccess) return fail_hip(e, "env kernel launch");
+    return MARL_OK;
+}
+
+extern "C" int marl_env_reset(marl_env_t* env, void* d_state, float* d_obs, const uint8_t* d_spawn_override,
+                              const uint8_t* d_dir_override, void* stream) {
+    return run_env_kernel(env, d_state, nullptr, 0, nullptr, d_spawn_override, d_dir_override, d_obs, nullptr, nullptr,
+                          nullptr, 1, stream);
+}
+
+extern "C" int marl_env_step(marl_env_t* env, void* d_state, const void* d_actions, int action_elem_size, float* d_obs,
+                             float* d_rewards, uint8_t* d_terminated, uint8_t* d_truncated,
+                             const uint8_t* d_prio_override, void* stream) {
+    if (!d_actions || !d_rewards || !d_terminated || !d_truncated)
+        return fail(MARL_ERR_INVALID, "actions / rewards / terminated / truncated must not be NULL");
+    if (action_elem_size != 1 && action_elem_size != 4 && action_elem_size != 8)
+        return fail(MARL_ERR_INVALID, "action_elem_size must be 1, 4 or 8");
+    if (((uintptr_t)d_actions & (uintptr_t)(action_elem_size - 1)) != 0)
+        return fail(MARL_ERR_INVALID, "d_actions is not aligned to its element size");
+    if (((uintptr_t)d_rewards & 3u) != 0) return fail(MARL_ERR_INVALID, "d_rewards must be 4-byte aligned");
+    return run_env_kernel(env, d_state, d_actions, action_elem_size, d_prio_override, nullptr, nullptr, d_obs,
+                          d_rewards, d_terminated, d_truncated, 0, stream);
+}
+
+extern "C" int marl_env_featurize(marl_env_t* env, void* d_state, float* d_obs, void* stream) {
+    return run_env_kernel(env, d_state, nullptr, 0, nullptr, nullptr, nullptr, d_obs, nullptr, nullptr, nullptr, 2, stream);
+}
+
+extern "C" int marl_env_export_state(marl_env_t* env, const void* d_state, int32_t* d_agents, int32_t* d_pots,
+                                     uint8_t* d_items, int32_t* d_misc, void* stream) {
+    if (!env || !d_state || !d_agents || !d_items || !d_misc || (env->NP > 0 && !d_pots))
+        return fail(MARL_ERR_INVALID, "NULL argument to marl_env_export_state");
+    const int block = 128, grid = (env->P.E + block - 1) / block;
+    hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream), env->P, env->A,
+                       env->niw, env->ncell, env->d_tab, reinterpret_cast<const uint32_t*>(d_state), d_agents, d_pots,
+                       d_items, d_misc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "export kernel launch");
+}
+
+extern "C" int marl_env_import_state(marl_env_t* env, void* d_state, const int32_t* d_agents, const int32_t* d_pots,
+                                     const uint8_t* d_items, const int32_t* d_misc, void* stream) {
+    if (!env || !d_state || !d_agents || !d_items || !d_misc || (env->NP > 0 && !d_pots))
+        return fail(MARL_ERR_INVALID, "NULL argument to marl_env_import_state");
+    const int block = 128, grid = (env->P.E + block - 1) / block;
+    hipLaunchKernelGGL(import_kernel, dim3(grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream), env->P, env->A,
+                       env->niw, env->ncell, env->d_tab, reinterpret_cast<uint32_t*>(d_state), d_agents, d_pots, d_items,
+                       d_misc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "import kernel launch");
+}
+
+extern "C" int marl_row_sums(const float* d_x, int T, int N, double* d_sums, void* stream) {
+    if (!d_x || !d_sums || T <= 0 || N <= 0) return fail(MARL_ERR_INVALID, "bad argument to marl_row_sums");
+    hipError_t e = launch_row_sums(d_x, T, N, d_sums, nullptr, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "row_sum kernel launch");
+}
+
+extern "C" int marl_gae(const float* d_rewards, const float* d_dones, const float* d_values,
+                        const float* d_next_values, int T, int N, double gamma, double lam, float* d_adv, float* d_ret,
+                        int mode, float* d_reward_mean, int reward_mean_ready, void* stream) {
+    if (!d_rewards || !d_dones || !d_values || !d_next_values || !d_adv)
+        return fail(MARL_ERR_INVALID, "NULL argument to marl_gae");
+    if (T <= 0 || N <= 0) return fail(MARL_ERR_INVALID, "T and N must be positive");
+    if (mode != 0 && mode != 1) return fail(MARL_ERR_INVALID, "mode must be 0 (MAPPO) or 1 (CMAPPO)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 1) {
+        if (!d_reward_mean) return fail(MARL_ERR_INVALID, "mode 1 needs the d_reward_mean workspace (float32[T])");
+        if (!reward_mean_ready) {
+            hipError_t e = launch_row_sums(d_rewards, T, N, nullptr, d_reward_mean, s);
+            if (e != hipSuccess) return fail_hip(e, "row_sum kernel launch");
+        }
+    }
+    // Python forms gamma * lam in double; each scalar is rounded to float32 when it meets a tensor
+    hipError_t e = launch_gae(d_rewards, d_dones, d_values, d_next_values, T, N, (float)gamma, (float)(gamma * lam),
+                              d_adv, d_ret, mode, d_reward_mean, s);
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "gae kernel launch");
+}

@@ -1,0 +1,120 @@
+// Shared between host table builder and device kernels: constants, feature-block
+// geometry and the byte layout of the per-layout lookup blob that every workgroup
+// stages into LDS.
+#pragma once
+
+#include <stdint.h>
+
+namespace oc {
+
+// static cell types
+enum : uint32_t { WALL = 0, FLOOR = 1, COUNTER = 2, POT = 3, ONION_STACK = 4, PLATE_STACK = 5, DELIVERY = 6 };
+// items (held, lying on the floor, or placed on a counter)
+enum : uint32_t { NONE = 0, ONION = 1, PLATE = 2, SOUP = 3 };
+// feature sets: registered names at overcooked_config.py:14-28; only_direction: README.md:65
+enum : int { FEAT_GLOBAL = 0, FEAT_LOCAL = 1, FEAT_MINIMAL = 2, FEAT_MINIMAL_OTHER = 3, FEAT_ONLY_DIRECTION = 4 };
+// cardinal action set, index 6 = no-op, 2 = move left (tests/test_load.py:37-43)
+enum : uint32_t { ACT_UP = 0, ACT_DOWN = 1, ACT_LEFT = 2, ACT_RIGHT = 3, ACT_PICKUP_DROP = 4, ACT_TOGGLE = 5, ACT_NOOP = 6 };
+// directions, README.md:112
+enum : uint32_t { DIR_RIGHT = 0, DIR_DOWN = 1, DIR_LEFT = 2, DIR_UP = 3 };
+
+constexpr int POT_CAPACITY = 3;
+constexpr int COOK_TIME = 30;
+constexpr int MAX_CELLS = 256;
+constexpr int MAX_POTS = 8;
+constexpr int MAX_AGENTS = 4;
+
+// pot condition classes and where each lands in the two pot encodings.
+// An empty pot is row 0 of NextToPot and index 1 of the pot-feature status one-hot: both
+// pinned by states/agent_0_dropping_onion_state.npy; cooking = 2 and ready = 3 follow the
+// docstring at overcooked_features.py:23.
+enum : uint32_t { POT_EMPTY = 0, POT_PARTIAL = 1, POT_COOKING = 2, POT_READY = 3 };
+constexpr uint32_t NEXT_TO_POT_ROW_PACKED = 0x3210;    // nibble k = row of class k
+constexpr uint32_t POT_STATUS_INDEX_PACKED = 0x3201;   // nibble k = one-hot index of class k
+// OvercookedInventory one-hot index per item (onion = 0 pinned by the golden vector)
+constexpr uint32_t INVENTORY_INDEX_PACKED = 0x1200;    // nibble item -> index: onion 0, plate 2, soup 1
+
+// Geometry of one agent's feature block (overcooked_features.py:38-78, :239-254, :291-298).
+template <int A, int FEAT>
+struct FeatGeom {
+    static constexpr bool kFull = (FEAT == FEAT_GLOBAL || FEAT == FEAT_LOCAL);
+    static constexpr bool kOthers = kFull || FEAT == FEAT_MINIMAL_OTHER;
+    static constexpr bool kSpatial = FEAT != FEAT_ONLY_DIRECTION;
+    static constexpr int O_DIR = 0;
+    static constexpr int O_INV = 4;
+    static constexpr int O_NEXT_COUNTER = 7;
+    static constexpr int O_NEXT_POT = 11;
+    // full sets only
+    static constexpr int O_ONION = 27;
+    static constexpr int O_PLATE = 35;
+    static constexpr int O_PLATE_STACK = 43;
+    static constexpr int O_ONION_STACK = 47;
+    static constexpr int O_SOUP = 51;
+    static constexpr int O_DELIVERY = 59;
+    static constexpr int O_COUNTER = 63;
+    static constexpr int O_POT0 = 71;
+    static constexpr int O_POT1 = 82;
+    static constexpr int O_OTHERS = kFull ? 93 : 27;
+    static constexpr int O_POS = O_OTHERS + (kOthers ? 2 * (A - 1) : 0);
+    static constexpr int O_CAN_MOVE = O_POS + 2;
+    static constexpr int BLK = kSpatial ? O_CAN_MOVE + 4 : 4;
+    static constexpr int NW = (BLK + 3) / 4;  // block padded to dwords
+    static constexpr int D = (FEAT == FEAT_GLOBAL) ? A * BLK : BLK;
+};
+
+inline int block_dim(int A, int feat) {
+    switch (feat) {
+        case FEAT_GLOBAL:
+        case FEAT_LOCAL: return 99 + 2 * (A - 1);
+        case FEAT_MINIMAL: return 33;
+        case FEAT_MINIMAL_OTHER: return 33 + 2 * (A - 1);
+        case FEAT_ONLY_DIRECTION: return 4;
+    }
+    return -1;
+}
+
+// ---- lookup blob (bytes) ----
+constexpr int TAB_CELLTYPE = 0;        // u8[256]
+constexpr int TAB_SLOT_OF_CELL = 256;  // u8[256], 0xFF = cell cannot hold an item
+constexpr int TAB_POT_OF_CELL = 512;   // u8[256]
+constexpr int TAB_FIDX_OF_CELL = 768;  // u8[256], index among floor cells
+constexpr int TAB_CELL_RC = 1024;      // u16[256], (row << 8) | col
+constexpr int TAB_CELL_OF_SLOT = 1536; // u8[256]
+constexpr int TAB_FLOOR_CELL = 1792;   // u8[256], floor cells in scan order
+constexpr int TAB_SPAWN_CELL = 2048;   // u8[256], '+' cells in scan order
+constexpr int TAB_POT_ORDER = 2304;    // u8[256][2], two nearest pots per cell (0xFF = none)
+constexpr int TAB_POT_CELL = 2816;     // u8[8]
+constexpr int TAB_POSTAB = 2832;       // i8[nfloor][NW*4] static part of the block per floor cell
+
+struct EnvParams {
+    int E;            // envs in this shard
+    int W;            // grid width
+    int NP;           // pots
+    int nslots;       // cells that can hold an item
+    int nfloor;
+    int nspawn;
+    int max_steps;
+    int tab_bytes;    // size of the lookup blob, multiple of 16
+    int dist_metric;  // 0 = L1, 1 = squared L2
+    uint32_t seed_key;          // mix of the 64-bit seed
+    uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard
+};
+
+// per-env packed state, struct-of-arrays: word w of env e lives at state[w * E + e]
+//   word 0: t (bits 0-15)
+//   word 1: RNG draw counter
+//   word 2 [,3]: pots, one byte each: count (bits 0-1) | timer (bits 2-6); word 3 only if NP > 4
+//   then (A+1)/2 agent words, 16 bits per agent: cell (0-7) | dir (8-9) | inv (10-11)
+//   then NIW item words, 2 bits per item slot
+inline int pot_words(int NP) { return NP > 4 ? 2 : 1; }
+inline int agent_words(int A) { return (A + 1) / 2; }
+inline int item_words_exact(int nslots) { return (nslots + 15) / 16; }
+inline int item_words_padded(int nslots) {
+    int w = item_words_exact(nslots);
+    return w <= 1 ? 1 : w <= 2 ? 2 : w <= 4 ? 4 : 8;
+}
+inline int state_words(int A, int NP, int nslots) {
+    return 2 + pot_words(NP) + agent_words(A) + item_words_padded(nslots);
+}
+
+}  // namespace oc

@@ -1,0 +1,270 @@
+"""Batched Overcooked vector env on MI355X behind the reference's vec-env surface.
+
+Mirrors what the reference's drivers touch:
+  * ``make_env(num_agents, layout, feature, render_mode)``           main.py:29-64
+  * ``make_vector_env(num_envs, overcooked_env)``                     main.py:66-96
+  * ``vec.num_envs == E * A``, ``vec.single_observation_space.shape == (D,)``,
+    ``vec.single_action_space.n == 7``                                main.py:92-93,186,195-196
+  * ``vec.reset() -> (obs_dict, info)``, ``vec.step(actions) ->
+    (obs_dict, rewards, terminated, truncated, info)`` with rows env-major and observations
+    under ``'n_agent_overcooked_features'``                           agent_environment.py:34-36,50-53,88,106-107
+
+All simulation and featurisation happens in libmarl_amd.so (HIP, gfx950); this module only
+owns device buffers (torch tensors) and argument checking.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .layouts import get_layout
+from .spaces import Box, Dict, Discrete
+
+OBS_KEY = "n_agent_overcooked_features"  # overcooked_features.py:103
+
+FEATURE_IDS = {
+    "global_obs": 0,                          # overcooked_config.py:14-16
+    "local_obs": 1,                           # overcooked_config.py:18-20
+    "Minimal_spatial": 2,                     # overcooked_config.py:26-28
+    "Minimal_spatial_other_agent_aware": 3,   # overcooked_config.py:22-24
+    "only_direction": 4,                      # README.md:65 (AgentDir only, README.md:112)
+}
+NUM_ACTIONS = 7  # cardinal_actions, overcooked_config.py:79
+
+
+def block_dim(feature: str, num_agents: int) -> int:
+    fid = FEATURE_IDS[feature]
+    if fid in (0, 1):
+        return 99 + 2 * (num_agents - 1)
+    if fid == 2:
+        return 33
+    if fid == 3:
+        return 33 + 2 * (num_agents - 1)
+    return 4
+
+
+def obs_dim(feature: str, num_agents: int) -> int:
+    b = block_dim(feature, num_agents)
+    return num_agents * b if feature == "global_obs" else b
+
+
+class OvercookedEnvSpec:
+    """What ``make_env`` returns: the single-env description the reference reads
+    (``observation_spaces[i][OBS_KEY].shape``, ``action_spaces[i].n``, ``config["num_agents"]``:
+    main.py:206-207,295)."""
+
+    def __init__(self, num_agents: int, layout: str, feature: str, max_steps: int = 1000, render_mode=None):
+        if feature not in FEATURE_IDS:
+            raise KeyError(f"unknown feature {feature!r}; known: {sorted(FEATURE_IDS)}")
+        self.layout_rows = get_layout(layout)
+        # overcooked_config.py:68-110 with main.py:47-50 applied
+        self.config = {
+            "name": "NAgentOvercooked-V0",
+            "num_agents": int(num_agents),
+            "action_set": "cardinal_actions",
+            "features": feature,
+            "rewards": ["onion_in_pot_reward", "soup_in_dish_reward", "delivery_reward"],
+            "scope": "overcooked",
+            "grid": {"layout": layout},
+            "max_steps": int(max_steps),
+        }
+        self.render_mode = render_mode
+        self.agent_ids = list(range(num_agents))
+        self.possible_agents = list(self.agent_ids)
+        d = obs_dim(feature, num_agents)
+        self.observation_spaces = {
+            i: Dict({OBS_KEY: Box(-np.inf, np.inf, (d,), np.float32)}) for i in self.agent_ids
+        }
+        self.action_spaces = {i: Discrete(NUM_ACTIONS) for i in self.agent_ids}
+
+
+def make_env(num_agents=4, layout="large_overcooked_layout", feature="global_obs", render_mode=None, max_steps=1000):
+    """main.py:29-64."""
+    return OvercookedEnvSpec(num_agents, layout, feature, max_steps=max_steps, render_mode=render_mode)
+
+
+def make_vector_env(num_envs, overcooked_env: OvercookedEnvSpec, **kwargs):
+    """main.py:66-96: E copies of the env, agents flattened to rows, one reset issued."""
+    vec = BatchedOvercookedVecEnv(
+        overcooked_env.layout_rows,
+        overcooked_env.config["num_agents"],
+        overcooked_env.config["features"],
+        num_envs,
+        max_steps=overcooked_env.config["max_steps"],
+        **kwargs,
+    )
+    vec.reset()
+    return vec
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class BatchedOvercookedVecEnv:
+    """E Overcooked envs with A agents each, resident on one GPU.
+
+    ``numpy_io=True`` makes reset/step accept and return numpy arrays exactly like the
+    reference's multiprocess vector env (so ``agent_environment.py``-shaped loops run
+    unchanged); the default hands out device tensors and never leaves the GPU.
+    """
+
+    def __init__(self, layout_rows, num_agents, feature="global_obs", num_envs=1, max_steps=1000, seed=0,
+                 env_index_base=0, device=None, numpy_io=False, dist_metric=0):
+        if isinstance(layout_rows, str):
+            layout_rows = get_layout(layout_rows)
+        if feature not in FEATURE_IDS:
+            raise KeyError(f"unknown feature {feature!r}; known: {sorted(FEATURE_IDS)}")
+        if not torch.cuda.is_available():
+            raise _lib.MarlAmdError("BatchedOvercookedVecEnv needs a HIP device (there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._L = _lib.lib()
+        self.E, self.A = int(num_envs), int(num_agents)
+        self.feature = feature
+        self.numpy_io = bool(numpy_io)
+        self.layout_rows = list(layout_rows)
+        self.H, self.W = len(layout_rows), len(layout_rows[0])
+        rows = (ctypes.c_char_p * len(layout_rows))(*[r.encode() for r in layout_rows])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.marl_env_create(ctypes.byref(handle), rows, len(layout_rows), self.A,
+                                               FEATURE_IDS[feature], int(max_steps), self.E, int(seed),
+                                               int(env_index_base), int(dist_metric)), "marl_env_create")
+        self._h = handle
+        self.D = self._L.marl_env_obs_dim(self._h)
+        self.NP = self._L.marl_env_num_pots(self._h)
+        self.state_words = self._L.marl_env_state_words(self._h)
+        self.N = self.E * self.A
+        assert self.D == obs_dim(feature, self.A)
+        # the reference's vec env reports rows, not games, as num_envs (main.py:186)
+        self.num_envs = self.N
+        self.single_observation_space = Box(-np.inf, np.inf, (self.D,), np.float32)
+        self.single_action_space = Discrete(NUM_ACTIONS)
+        self.observation_space = Dict({OBS_KEY: self.single_observation_space})
+        self.action_space = self.single_action_space
+        self.state = torch.zeros((self.state_words, self.E), dtype=torch.int32, device=self.device)
+        self._closed = False
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new_obs(self, out):
+        if out is None:
+            return torch.empty((self.N, self.D), dtype=torch.float32, device=self.device)
+        if out.shape != (self.N, self.D) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"out must be a contiguous float32 ({self.N}, {self.D}) tensor on {self.device}")
+        if out.data_ptr() % 16:
+            raise ValueError("out must be 16-byte aligned")
+        return out
+
+    def _u8(self, x, name):
+        if x is None:
+            return None
+        t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(self.device, torch.uint8).contiguous()
+        if t.numel() != self.N:
+            raise ValueError(f"{name} must have {self.E}x{self.A} entries")
+        return t
+
+    def _wrap_obs(self, obs):
+        return {OBS_KEY: obs.cpu().numpy() if self.numpy_io else obs}
+
+    # ------------------------------------------------------------------
+    def reset(self, seed=None, options=None, out=None, spawn_override=None, dir_override=None):
+        """agent_environment.py:34,88: every env restarts.  ``seed`` is accepted for API
+        compatibility and ignored (the reference never passes one; the key was fixed at
+        construction)."""
+        obs = self._new_obs(out)
+        so, do = self._u8(spawn_override, "spawn_override"), self._u8(dir_override, "dir_override")
+        _lib.check(self._L.marl_env_reset(self._h, _ptr(self.state), _ptr(obs), _ptr(so), _ptr(do), self._stream()),
+                   "marl_env_reset")
+        return self._wrap_obs(obs), {}
+
+    def step(self, actions, out=None, prio_override=None):
+        """agent_environment.py:50."""
+        if torch.is_tensor(actions):
+            act = actions.to(self.device)
+        else:
+            act = torch.as_tensor(np.asarray(actions)).to(self.device)
+        if act.dtype not in (torch.int64, torch.int32, torch.uint8):
+            act = act.to(torch.int64)
+        act = act.contiguous()
+        if act.numel() != self.N:
+            raise ValueError(f"actions must have {self.N} entries, got {tuple(act.shape)}")
+        obs = self._new_obs(out)
+        rew = torch.empty(self.N, dtype=torch.float32, device=self.device)
+        term = torch.empty(self.N, dtype=torch.bool, device=self.device)
+        trunc = torch.empty(self.N, dtype=torch.bool, device=self.device)
+        po = self._u8(prio_override, "prio_override")
+        _lib.check(self._L.marl_env_step(self._h, _ptr(self.state), _ptr(act), act.element_size(), _ptr(obs),
+                                         _ptr(rew), _ptr(term), _ptr(trunc), _ptr(po), self._stream()),
+                   "marl_env_step")
+        if self.numpy_io:
+            return self._wrap_obs(obs), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), {}
+        return {OBS_KEY: obs}, rew, term, trunc, {}
+
+    def featurize(self, out=None):
+        obs = self._new_obs(out)
+        _lib.check(self._L.marl_env_featurize(self._h, _ptr(self.state), _ptr(obs), self._stream()),
+                   "marl_env_featurize")
+        return obs
+
+    # ------------------------------------------------------------------
+    def export_state(self):
+        """Canonical snapshot as CPU numpy arrays (see include/marl_amd.h)."""
+        agents = torch.empty((self.E, self.A, 4), dtype=torch.int32, device=self.device)
+        pots = torch.empty((self.E, max(self.NP, 1), 2), dtype=torch.int32, device=self.device)
+        items = torch.empty((self.E, self.H * self.W), dtype=torch.uint8, device=self.device)
+        misc = torch.empty((self.E, 2), dtype=torch.int32, device=self.device)
+        pots_arg = pots[:, : self.NP].contiguous() if self.NP else pots
+        _lib.check(self._L.marl_env_export_state(self._h, _ptr(self.state), _ptr(agents), _ptr(pots_arg), _ptr(items),
+                                                 _ptr(misc), self._stream()), "marl_env_export_state")
+        return {"agents": agents.cpu().numpy(), "pots": pots_arg[:, : self.NP].cpu().numpy(),
+                "items": items.cpu().numpy(), "misc": misc.cpu().numpy()}
+
+    def import_state(self, snap):
+        agents = np.ascontiguousarray(snap["agents"], np.int32).reshape(self.E, self.A, 4)
+        pots = np.ascontiguousarray(snap["pots"], np.int32).reshape(self.E, self.NP, 2)
+        items = np.ascontiguousarray(snap["items"], np.uint8).reshape(self.E, self.H * self.W)
+        misc = np.ascontiguousarray(snap["misc"], np.int32).reshape(self.E, 2)
+        self._validate_snapshot(agents, pots, items, misc)
+        d = [torch.from_numpy(x).to(self.device) for x in (agents, pots if self.NP else np.zeros((1,), np.int32), items, misc)]
+        _lib.check(self._L.marl_env_import_state(self._h, _ptr(self.state), _ptr(d[0]), _ptr(d[1]), _ptr(d[2]),
+                                                 _ptr(d[3]), self._stream()), "marl_env_import_state")
+        torch.cuda.current_stream(self.device).synchronize()  # host staging buffers die with this frame
+
+    def _validate_snapshot(self, agents, pots, items, misc):
+        grid = np.array([list(r) for r in self.layout_rows])
+        floor = np.isin(grid, [" ", "+"]).reshape(-1)
+        holder = floor | (grid == "C").reshape(-1)
+        cell = agents[..., 0] * self.W + agents[..., 1]
+        if (agents[..., 0] < 0).any() or (agents[..., 0] >= self.H).any() or (agents[..., 1] < 0).any() \
+                or (agents[..., 1] >= self.W).any() or not floor[cell].all():
+            raise ValueError("snapshot puts an agent off the floor")
+        if ((agents[..., 2] < 0) | (agents[..., 2] > 3) | (agents[..., 3] < 0) | (agents[..., 3] > 3)).any():
+            raise ValueError("snapshot has an out-of-range direction or inventory code")
+        if self.A > 1 and (np.sort(cell, axis=1)[:, 1:] == np.sort(cell, axis=1)[:, :-1]).any():
+            raise ValueError("snapshot puts two agents on one cell")
+        if (items > 3).any() or (items[:, ~holder] != 0).any():
+            raise ValueError("snapshot has an item on a cell that cannot hold one")
+        if np.take_along_axis(items, cell, axis=1).any():
+            raise ValueError("snapshot has an item under an agent")
+        if self.NP and ((pots[..., 0] < 0) | (pots[..., 0] > 3) | (pots[..., 1] < 0) | (pots[..., 1] > 30)).any():
+            raise ValueError("snapshot has an out-of-range pot")
+        if ((misc[:, 0] < 0) | (misc[:, 0] > 65535)).any():
+            raise ValueError("snapshot has an out-of-range step counter")
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if not self._closed and self._h:
+            self._L.marl_env_destroy(self._h)
+            self._closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
