@@ -1,0 +1,152 @@
+"""Multi-agent PPO learner with decentralised critic, interface of the reference's
+``agents/MAPPO.py`` (act / add_to_buffer / compute_gae / update).
+
+What changed relative to the reference, and only this:
+  * ``compute_gae`` runs as one HIP kernel (libmarl_amd.so) instead of a Python loop over T
+    (agents/MAPPO.py:98-114); value targets (``:144``) come out of the same launch;
+  * minibatch indices are drawn on the device (``torch.randperm``) unless
+    ``shuffle="numpy"`` asks for the reference's ``np.random.shuffle`` (``:159``);
+  * with more than one rank, gradients are averaged by one flat all-reduce between
+    ``loss.backward()`` and ``clip_grad_norm_`` (``:207-208``);
+  * scalar logging does not force a device sync per minibatch.
+The PPO objective itself (``:170-209``: clipped surrogate, unclipped value loss, entropy bonus,
+no advantage normalisation) is the reference's.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .. import dist_utils
+from ..gae import compute_gae as _gae_kernel
+
+
+class MAPPO:
+    centralised = False
+
+    def __init__(self, env, optimzer, policy, buffer, single_agent_obs, single_agent_action, batch_size=1,
+                 num_mini_batches=4, num_agents=4, ppo_epoch=10, clip_param=0.2, value_loss_coef=0.5,
+                 entropy_coef=0.01, max_grad_norm=0.5, gamma=0.99, lam=0.95, save_path=None, log_dir=None,
+                 log=False, args=None, shuffle="device", writer=None):
+        self.env, self.optimizer, self.policy, self.buffer = env, optimzer, policy, buffer
+        self.num_agents = num_agents
+        self.single_agent_obs, self.single_agent_action = single_agent_obs, single_agent_action
+        self.device = next(policy.parameters()).device if policy is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.batch_size = batch_size
+        self.mini_batch_size = batch_size // num_mini_batches
+        self.ppo_epoch, self.clip_param = ppo_epoch, clip_param
+        self.value_loss_coef, self.entropy_coef, self.max_grad_norm = value_loss_coef, entropy_coef, max_grad_norm
+        self.gamma, self.lam = gamma, lam
+        self.save_path, self.log_dir, self.args, self.log = save_path, log_dir, args, log
+        self.shuffle = shuffle
+        self.summary_writer = writer
+        self.num_gradient_steps = 0
+        self.last_stats = {}
+        self._reducer = dist_utils.FlatGradAllReducer(policy.parameters()) if policy is not None else None
+
+    # ------------------------------------------------------------------ acting
+    def act(self, obs):
+        """agents/MAPPO.py:58-77: sample actions without tracking gradients."""
+        with torch.no_grad():
+            obs = obs.to(self.device)
+            if self.centralised:
+                return self.policy.get_action_and_value(obs, joint_obs=obs.view(1, -1))
+            return self.policy.get_action_and_value(obs)
+
+    def add_to_buffer(self, obs, actions, rewards, dones, logprobs, values):
+        self.buffer.add(obs, actions, rewards, dones, logprobs, values)
+
+    # ------------------------------------------------------------------ GAE
+    def compute_gae(self, rewards, dones, values, next_values, want_returns=False):
+        """agents/MAPPO.py:82-114.  Returns advantages (and value targets when asked)."""
+        adv, ret = _gae_kernel(rewards, dones, values, next_values, self.gamma, self.lam, centralised=False,
+                               want_returns=want_returns)
+        return (adv, ret) if want_returns else adv
+
+    def compute_value_loss(self, target, newvalue):
+        return 0.5 * ((newvalue - target) ** 2).mean()  # agents/MAPPO.py:243-248
+
+    def _bootstrap(self, next_obs):
+        rows = self.buffer.rewards_buff.shape[1]
+        return self.policy.get_value(next_obs).reshape(1, rows)  # agents/MAPPO.py:133
+
+    # ------------------------------------------------------------------ update
+    def update(self, next_obs):
+        """agents/MAPPO.py:116-233."""
+        buf = self.buffer
+        with torch.no_grad():
+            next_values = self._bootstrap(next_obs.to(self.device)).float()
+        advantages, value_target = self.compute_gae(buf.rewards_buff, buf.dones_buff, buf.values_buff, next_values,
+                                                    want_returns=True)
+        obs_shape = tuple(self.env.single_observation_space.shape)
+        b_obs = buf.obs_buff.reshape((-1,) + obs_shape)
+        b_logprobs = buf.logprobs_buff.reshape(-1)
+        b_actions = buf.actions_buff.reshape(-1).long()
+        b_advantages = advantages.reshape(-1)
+        b_value_target = value_target.reshape(-1)
+        total = b_logprobs.numel()
+        if self.batch_size != total:
+            raise ValueError(f"batch_size {self.batch_size} != stored samples {total}")
+
+        sums = torch.zeros(6, dtype=torch.float64, device=self.device)  # v, pg, ent, kl, old_kl, clipfrac
+        count = 0
+        for _ in range(self.ppo_epoch):
+            if self.shuffle == "numpy":
+                idx = np.arange(total)
+                np.random.shuffle(idx)
+                perm = torch.from_numpy(idx).to(self.device)
+            else:
+                perm = torch.randperm(total, device=self.device)
+            for start in range(0, total, self.mini_batch_size):
+                mb = perm[start:min(start + self.mini_batch_size, total)]
+                _, newlogprob, entropy, newvalue = self.policy.get_action_and_value(b_obs[mb], b_actions[mb])
+                logratio = newlogprob - b_logprobs[mb]
+                ratio = logratio.exp()
+                mb_adv = b_advantages[mb]
+                pg_loss = torch.max(-mb_adv * ratio,
+                                    -mb_adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+                v_loss = self.compute_value_loss(b_value_target[mb], newvalue.squeeze())
+                entropy_loss = entropy.mean()
+                loss = pg_loss - self.entropy_coef * entropy_loss + v_loss * self.value_loss_coef
+
+                self.optimizer.zero_grad()
+                loss.backward()
+                self._reducer()  # RCCL: one flat all-reduce, no-op on a single rank
+                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.optimizer.step()
+
+                with torch.no_grad():
+                    sums += torch.stack([v_loss, pg_loss, entropy_loss, ((ratio - 1) - logratio).mean(),
+                                         (-logratio).mean(),
+                                         ((ratio - 1.0).abs() > self.clip_param).float().mean()]).double()
+                count += 1
+        self.num_gradient_steps += 1
+        stats = (sums / max(count, 1)).tolist()  # one sync per update
+        self.last_stats = dict(zip(("value_loss", "policy_loss", "entropy", "approx_kl", "old_approx_kl", "clipfrac"),
+                                   stats))
+        if self.log and self.summary_writer is not None:
+            self.summary_writer.add_scalar("charts/learning_rate", self.optimizer.param_groups[0]["lr"],
+                                           self.num_gradient_steps)
+            for k, v in self.last_stats.items():
+                self.summary_writer.add_scalar(f"losses/{k}", v, self.num_gradient_steps)
+        if self.save_path is not None and self.num_gradient_steps % 100 == 0 and dist_utils.get_rank() == 0:
+            self.save_model()
+        buf.reset()
+
+    def checkpoint_name(self):
+        a = self.args
+        kind = "centralised" if getattr(a, "centralised", False) else "decentralised"  # agents/MAPPO.py:227-228
+        return f"{kind}_policy_{a.num_agents}_agents_{a.layout}_seed_{a.seed}.pth"
+
+    def save_model(self):
+        os.makedirs(self.save_path, exist_ok=True)
+        path = os.path.join(self.save_path, self.checkpoint_name())
+        torch.save(self.policy.state_dict(), path)
+        return path
+
+    def get_grad_norm(self, module):
+        sq = [p.grad.detach().norm(2) ** 2 for p in module.parameters() if p.grad is not None]
+        return float(torch.stack(sq).sum().sqrt()) if sq else 0.0

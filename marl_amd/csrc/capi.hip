@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -338,8 +339,11 @@ extern "C" int marl_env_step(marl_env_t* env, void* d_state, const void* d_actio
     if (((uintptr_t)d_actions & (uintptr_t)(action_elem_size - 1)) != 0)
         return fail(MARL_ERR_INVALID, "d_actions is not aligned to its element size");
     if (((uintptr_t)d_rewards & 3u) != 0) return fail(MARL_ERR_INVALID, "d_rewards must be 4-byte aligned");
+    // MARL_AMD_ABLATE=1|2 (profiling only): time the simulation without the store stream, or
+    // the store stream without the simulation; results are then meaningless
+    static const int ablate = [] { const char* v = getenv("MARL_AMD_ABLATE"); return v ? atoi(v) & 31 : 0; }();
     return run_env_kernel(env, d_state, d_actions, action_elem_size, d_prio_override, nullptr, nullptr, d_obs,
-                          d_rewards, d_terminated, d_truncated, 0, stream);
+                          d_rewards, d_terminated, d_truncated, ablate << 8, stream);
 }
 
 extern "C" int marl_env_featurize(marl_env_t* env, void* d_state, float* d_obs, void* stream) {

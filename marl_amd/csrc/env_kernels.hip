@@ -566,7 +566,9 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict_
     const size_t row = row0 + lane;
     const bool active = row < N;
 
-    if (active) {
+    const int ablate = mode >> 8;  // profiling aid: 1 = skip the store stream, 2 = skip the simulation
+    mode &= 0xFF;
+    if (active && !(ablate & 2)) {
         const int e = (int)(row / A);
         const uint32_t i = (uint32_t)(row % A);
         EnvState<A, NIW> s;
@@ -585,7 +587,8 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict_
                                              : (uint32_t) reinterpret_cast<const uint8_t*>(actions)[r];
             });
             uint32_t onion_mask, dish_mask, deliver_mask;
-            step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
+            onion_mask = dish_mask = deliver_mask = 0;
+            if (!(ablate & 4)) step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
             // rewards accumulate as Python floats in the config's list order
             // [onion_in_pot 0.1, soup_in_dish 0.3, delivery 1.0 shared] (overcooked_config.py:96)
             double r = 0.0;
@@ -606,8 +609,11 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict_
         }
 
         Block<NW> blk;
-        build_block<A, FEAT, NIW>(blk, s, T, P, i);
-        if constexpr (FEAT == FEAT_GLOBAL) {
+        if (!(ablate & 8)) build_block<A, FEAT, NIW>(blk, s, T, P, i);
+        else static_for<0, NW>([&](auto K) { blk.w[K.value] = s.items[0]; });
+        if (ablate & 16) {
+            if (blk.w[0] == 0x12345678u) img[lane] = 1;
+        } else if constexpr (FEAT == FEAT_GLOBAL) {
             // my block goes into every row of my env: first in my own, after the lower ids elsewhere
             const uint32_t env_lane0 = (uint32_t)lane - i;
             static_for<0, A>([&](auto J) {
@@ -622,7 +628,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict_
     __syncthreads();
 
     // stream the wave's rows out: 4 int8 -> 4 floats -> one 16-byte store per lane
-    if (row0 < N) {
+    if (row0 < N && !(ablate & 1)) {
         const size_t rows_here = (N - row0) < 64 ? (N - row0) : 64;
         const uint32_t nchunk = (uint32_t)(rows_here * D) / 4;  // 64*D is a multiple of 4; tails handled below
         const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);

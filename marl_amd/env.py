@@ -124,6 +124,7 @@ class BatchedOvercookedVecEnv:
         self._L = _lib.lib()
         self.E, self.A = int(num_envs), int(num_agents)
         self.feature = feature
+        self.max_steps = int(max_steps)
         self.numpy_io = bool(numpy_io)
         self.layout_rows = list(layout_rows)
         self.H, self.W = len(layout_rows), len(layout_rows[0])
@@ -205,6 +206,14 @@ class BatchedOvercookedVecEnv:
         if self.numpy_io:
             return self._wrap_obs(obs), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), {}
         return {OBS_KEY: obs}, rew, term, trunc, {}
+
+    def step_into(self, actions, obs, rewards, terminated, truncated, prio_override=None):
+        """Allocation-free step for device-resident loops and graph capture: every argument is
+        a preallocated tensor on this env's device (actions int64/int32/uint8 [N]; obs float32
+        [N, D]; rewards float32 [N]; terminated/truncated bool or uint8 [N])."""
+        _lib.check(self._L.marl_env_step(self._h, _ptr(self.state), _ptr(actions), actions.element_size(), _ptr(obs),
+                                         _ptr(rewards), _ptr(terminated), _ptr(truncated), _ptr(prio_override),
+                                         self._stream()), "marl_env_step")
 
     def featurize(self, out=None):
         obs = self._new_obs(out)

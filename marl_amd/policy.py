@@ -1,0 +1,60 @@
+"""Actor-critic MLP with the parameter names of the reference's ``model.Agent``
+(model.py:11-68), so that checkpoints interchange: ``network.{0,2}`` (obs -> 512 -> 256,
+ReLU), ``actor`` (256 -> n_actions), ``critic`` (256 -> 1) and ``centralised_critics.{0,2,4}``
+(obs_dim * num_agents * num_envs -> 512 -> 256 -> 1).  All layers start orthogonal with gain
+sqrt(2) and zero bias (model.py:6-9).  The matrix products run on PyTorch-ROCm (rocBLAS /
+hipBLASLt); nothing here is hand-written HIP."""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+from torch.distributions import Categorical
+
+
+def _ortho(linear: nn.Linear, gain: float = math.sqrt(2.0), bias: float = 0.0) -> nn.Linear:
+    nn.init.orthogonal_(linear.weight, gain)
+    nn.init.constant_(linear.bias, bias)
+    return linear
+
+
+def _mlp(sizes, final_activation):
+    layers = []
+    for k in range(len(sizes) - 1):
+        layers.append(_ortho(nn.Linear(sizes[k], sizes[k + 1])))
+        if k < len(sizes) - 2 or final_activation:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class Agent(nn.Module):
+    def __init__(self, obs_space, action_space, num_agents=4, num_envs=1):
+        super().__init__()
+        self.obs_space, self.action_space = obs_space, action_space
+        self.num_agents, self.num_envs = int(num_agents), int(num_envs)
+        d = int(obs_space.shape[0])
+        self.network = _mlp([d, 512, 256], final_activation=True)
+        self.actor = _ortho(nn.Linear(256, int(action_space.n)))
+        self.critic = _ortho(nn.Linear(256, 1))
+        # model.py:28-34: one value for the concatenated observations of every row
+        self.centralised_critics = _mlp([d * self.num_agents * self.num_envs, 512, 256, 1], final_activation=False)
+
+    def get_value(self, x, joint_obs=None):
+        if joint_obs is not None:
+            want = int(self.obs_space.shape[0]) * self.num_agents * self.num_envs
+            if joint_obs.shape[1] != want:
+                raise ValueError(f"joint_obs has width {joint_obs.shape[1]}, expected {want}")
+            return self.centralised_critics(joint_obs)
+        return self.critic(self.network(x))
+
+    def get_action_and_value(self, x, action=None, joint_obs=None):
+        hidden = self.network(x)
+        dist = Categorical(logits=self.actor(hidden))
+        if action is None:
+            action = dist.sample()
+        value = self.centralised_critics(joint_obs) if joint_obs is not None else self.critic(hidden)
+        return action, dist.log_prob(action), dist.entropy(), value
+
+    def get_prob(self, x):
+        return Categorical(logits=self.actor(self.network(x)))

@@ -1,0 +1,137 @@
+"""Device-resident rollout driver, counterpart of the reference's
+``agent_environment.agent_environment_loop`` (agent_environment.py:12-130).
+
+Same control flow -- act, step, count reward events, store, global reset when env 0 finishes,
+update every ``num_steps`` -- with the per-step host round trips removed:
+  * observations, rewards and done flags never leave the GPU (the reference does two
+    host-to-device copies, one device-to-host copy and a Python loop over rows per step,
+    agent_environment.py:50,63,106-107);
+  * the env kernel writes the next observation straight into the rollout store's next row;
+  * episode statistics accumulate on the device and are read back once per episode.
+Episode statistics keep the reference's definition (agent_environment.py:66-76,86-104: the
+first env's agents only; a delivery is any reward >= 1, a plating == 0.3, an onion-in-pot
+== 0.1; the return is the sum over steps of the mean reward of those agents) and add the
+same quantities averaged over every env of every rank.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist_utils
+from .env import OBS_KEY
+
+
+class ScalarLog:
+    """Stand-in for tensorboard's SummaryWriter when tensorboard is not installed: keeps
+    scalars in memory (``.scalars[tag] = [(step, value), ...]``)."""
+
+    def __init__(self, log_dir=None):
+        self.log_dir = log_dir
+        self.scalars = {}
+
+    def add_scalar(self, tag, value, step):
+        self.scalars.setdefault(tag, []).append((int(step), float(value)))
+
+    def close(self):
+        pass
+
+
+def make_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter  # optional dependency
+
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:
+        return ScalarLog(log_dir)
+
+
+def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, args=None, writer=None,
+                           progress=False):
+    collect_steps = args.num_steps
+    A = agent.num_agents
+    N = args.num_envs * A
+    E = args.num_envs
+    if env.num_envs != N:
+        raise ValueError(f"env has {env.num_envs} rows, expected num_envs*num_agents = {N}")
+    log = bool(getattr(args, "log", False))
+    if log and writer is None:
+        writer = make_writer(log_dir)
+    max_steps = getattr(env, "max_steps", 1000)
+
+    episodes_reward, deliveries, platings, pottings = [], [], [], []
+    all_env = {"episode_return_all_envs": [], "deliveries_all_envs": [], "platings_all_envs": [],
+               "pottings_all_envs": []}
+    # [return(env0), delivery, plated, potted, return(all), delivery(all), plated(all), potted(all)]
+    acc = torch.zeros(8, dtype=torch.float64, device=device)
+    steps_in_episode = 0
+    num_episodes = 0
+    global_step = 0
+
+    buf = agent.buffer
+    obs = buf.obs_slot(0)
+    env.reset(out=obs)
+    dones = torch.zeros(N, dtype=torch.float32, device=device)
+    carry = torch.empty_like(obs)  # holds the observation that follows the last stored row
+    thirty = torch.tensor(0.3, dtype=torch.float32, device=device)
+    tenth = torch.tensor(0.1, dtype=torch.float32, device=device)
+
+    rng = range(num_update)
+    if progress:
+        try:
+            from tqdm import tqdm
+
+            rng = tqdm(rng)
+        except Exception:
+            pass
+    for _ in rng:
+        for step in range(collect_steps):
+            actions, logprobs, _, values = agent.act(obs)
+            nxt = buf.obs_slot(step + 1) if step + 1 < collect_steps else carry
+            _, rewards, terminated, truncated, _ = env.step(actions, out=nxt)
+
+            r0 = rewards[0:A]
+            rall = rewards.view(E, A)
+            acc += torch.stack([
+                r0.mean(), (r0 >= 1).any().float(), (r0 == thirty).any().float(), (r0 == tenth).any().float(),
+                rall.mean(), (rall >= 1).any(1).float().mean(), (rall == thirty).any(1).float().mean(),
+                (rall == tenth).any(1).float().mean()]).double()
+
+            agent.add_to_buffer(obs, actions, rewards, dones, logprobs, values.squeeze(1))
+            steps_in_episode += 1
+            if steps_in_episode >= max_steps:
+                # every env was stepped in lockstep and has just truncated; like the reference,
+                # restart all of them once more from the driver (agent_environment.py:86-88)
+                env.reset(out=nxt)
+                tot = acc.clone()
+                if dist_utils.world_size() > 1:
+                    dist_utils.all_reduce_sum_(tot[4:])
+                    tot[4:] /= dist_utils.world_size()
+                vals = tot.tolist()  # the one host sync per episode
+                episodes_reward.append(vals[0]); deliveries.append(vals[1]); platings.append(vals[2]); pottings.append(vals[3])
+                for k, v in zip(all_env, vals[4:]):
+                    all_env[k].append(v)
+                if log and writer is not None:
+                    writer.add_scalar("episode_rewards", vals[0], num_episodes)
+                    writer.add_scalar("freq/frequency_delivery_per_episode", vals[1], num_episodes)
+                    writer.add_scalar("freq/frequency_plated_per_episode", vals[2], num_episodes)
+                    writer.add_scalar("freq/frequency_ingredient_in_pot_per_episode", vals[3], num_episodes)
+                    writer.add_scalar("all_envs/episode_return", vals[4], num_episodes)
+                    writer.add_scalar("all_envs/deliveries_per_episode", vals[5], num_episodes)
+                acc.zero_()
+                steps_in_episode = 0
+                num_episodes += 1
+            obs = nxt
+            dones = (terminated | truncated).float()
+            global_step += 1
+        agent.update(obs)
+        # the stored rows restart at 0: the carried observation becomes row 0
+        buf.obs_slot(0).copy_(obs)
+        obs = buf.obs_slot(0)
+
+    freq = {
+        "frequency_delivery_per_episode": deliveries,
+        "frequency_plated_per_episode": platings,
+        "frequency_ingredient_in_pot_per_episode": pottings,
+    }
+    freq.update(all_env)
+    return episodes_reward, freq

@@ -1,0 +1,80 @@
+"""End-to-end rollout + GAE + PPO update on the GPU (small shapes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(argv):
+    from marl_amd import train
+
+    return train.main(argv)
+
+
+@pytest.mark.parametrize("algorithm,layout", [("mappo", "overcooked_cramped_room_v0"),
+                                              ("cmappo", "overcooked_forced_coordination_v0")])
+def test_training_runs_and_logs(tmp_path, algorithm, layout):
+    E, A, T = 16, 2, 32
+    updates = 4
+    returns, freq = _run([
+        "--num-agents", str(A), "--num-envs", str(E), "--layout", layout, "--num-steps", str(T),
+        "--num-minibatches", "4", "--total-steps", str(E * A * T * updates), "--ppo-epoch", "2",
+        "--algorithm", algorithm, "--max-steps", "50", "--data-path", str(tmp_path), "--seed", "3",
+    ])
+    # 4 updates x 32 steps = 128 steps = 2 full 50-step episodes
+    assert len(returns) == 2
+    assert all(np.isfinite(returns))
+    assert len(freq["episode_return_all_envs"]) == 2
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert any(n.endswith("_returns_seed_3.csv") for n in files)
+
+
+def test_rollout_buffer_matches_manual_loop():
+    """The driver's zero-copy observation hand-off stores exactly what a plain
+    step/copy loop would store."""
+    import types
+
+    from marl_amd.agents import MAPPO
+    from marl_amd.env import OBS_KEY, make_env, make_vector_env
+    from marl_amd.policy import Agent
+    from marl_amd.rollout import agent_environment_loop
+    from marl_amd.rollout_buffer import Buffer
+
+    dev = torch.device("cuda:0")
+    E, A, T = 8, 2, 16
+    env = make_env(A, "overcooked_cramped_room_v0", "global_obs", max_steps=10)
+
+    class Recorder(MAPPO):
+        def update(self, next_obs):  # keep what was collected, learn nothing
+            self.snap = {k: getattr(self.buffer, k).clone() for k in
+                         ("obs_buff", "actions_buff", "rewards_buff", "dones_buff")}
+            self.next_obs = next_obs.clone()
+            self.buffer.reset()
+
+    vec = make_vector_env(E, env, seed=9, device=dev)
+    torch.manual_seed(0)
+    net = Agent(vec.single_observation_space, vec.single_action_space, A, E).to(dev)
+    buf = Buffer(vec.D, A, E, max_size=T, device=dev)
+    args = types.SimpleNamespace(num_steps=T, num_envs=E, num_agents=A, log=False)
+    agent = Recorder(vec, None, net, buf, None, None, batch_size=E * A * T, num_agents=A, args=args)
+    torch.manual_seed(1)
+    agent_environment_loop(agent, vec, dev, num_update=1, args=args)
+
+    # replay by hand with the same action stream
+    vec2 = make_vector_env(E, env, seed=9, device=dev)
+    obs, _ = vec2.reset()
+    obs = obs[OBS_KEY]
+    dones = torch.zeros(E * A, device=dev)
+    steps_in_ep = 0
+    for t in range(T):
+        assert torch.equal(agent.snap["obs_buff"][t], obs), f"stored observation {t} differs"
+        assert torch.equal(agent.snap["dones_buff"][t], dones)
+        o, r, te, tr, _ = vec2.step(agent.snap["actions_buff"][t].long())
+        assert torch.equal(agent.snap["rewards_buff"][t], r)
+        steps_in_ep += 1
+        if steps_in_ep == 10:
+            o, _ = vec2.reset()
+            steps_in_ep = 0
+        obs, dones = o[OBS_KEY], (te | tr).float()
+    assert torch.equal(agent.next_obs, obs)
