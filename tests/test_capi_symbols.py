@@ -1,0 +1,45 @@
+"""The shared library loads without a GPU and exports every function include/marl_amd.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "marl_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(marl_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    from marl_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 15
+    assert sorted(_lib.EXPORTS) == names, "marl_amd/_lib.py binds a different set than the header declares"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"libmarl_amd.so does not export {missing}"
+
+
+def test_argument_errors_are_reported_without_touching_the_gpu():
+    from marl_amd import _lib
+
+    L = _lib.lib()
+    handle = ctypes.c_void_p()
+    rows = (ctypes.c_char_p * 3)(b"###", b"# #", b"###")
+    # 3 agents are not supported by the lane mapping; rejected before any HIP call
+    rc = L.marl_env_create(ctypes.byref(handle), rows, 3, 3, 0, 1000, 4, 0, 0, 0)
+    assert rc == -1 and b"num_agents" in L.marl_last_error()
+    rc = L.marl_env_create(ctypes.byref(handle), rows, 3, 2, 9, 1000, 4, 0, 0, 0)
+    assert rc == -1 and b"feature" in L.marl_last_error()
+    bad = (ctypes.c_char_p * 3)(b"###", b"#x#", b"###")
+    rc = L.marl_env_create(ctypes.byref(handle), bad, 3, 1, 0, 1000, 4, 0, 0, 0)
+    assert rc == -2 and b"unknown layout character" in L.marl_last_error()
+    open_grid = (ctypes.c_char_p * 3)(b"# #", b"# #", b"###")
+    rc = L.marl_env_create(ctypes.byref(handle), open_grid, 3, 1, 0, 1000, 4, 0, 0, 0)
+    assert rc == -2 and b"enclosed" in L.marl_last_error()
+    rc = L.marl_gae(None, None, None, None, 4, 4, 0.99, 0.95, None, None, 0, None, 0, None)
+    assert rc == -1
+    assert L.marl_env_obs_dim(None) == -1

@@ -78,3 +78,31 @@ def test_rollout_buffer_matches_manual_loop():
             steps_in_ep = 0
         obs, dones = o[OBS_KEY], (te | tr).float()
     assert torch.equal(agent.next_obs, obs)
+
+
+def test_numpy_io_mode_runs_a_reference_shaped_loop():
+    """The host-array mode accepts and returns what agent_environment.py:34-36,50-53,106-107
+    handles: numpy actions in, numpy obs dict / rewards / terminated / truncated out."""
+    from marl_amd.env import OBS_KEY, make_env, make_vector_env
+
+    dev = torch.device("cuda:0")
+    E, A = 16, 2
+    env = make_env(num_agents=A, layout="overcooked_cramped_room_v0", feature="global_obs", max_steps=20)
+    vec = make_vector_env(E, env, numpy_io=True, seed=2)
+    assert vec.num_envs == E * A
+    obs, info = vec.reset()
+    obs = torch.FloatTensor(obs[OBS_KEY]).to(dev)
+    assert obs.shape == (E * A,) + vec.single_observation_space.shape
+    n_done = 0
+    for t in range(45):
+        actions = torch.randint(0, vec.single_action_space.n, (E * A,), device=dev)
+        next_obs, rewards, terminated, truncated, info = vec.step(actions.cpu().numpy())
+        assert isinstance(rewards, np.ndarray) and rewards.dtype == np.float32 and rewards.shape == (E * A,)
+        assert terminated.shape == (E * A,) and truncated.shape == (E * A,)
+        rewards = torch.FloatTensor(rewards).to(dev)
+        dones = torch.tensor([terminated[i] or truncated[i] for i in range(E * A)]).to(dev)
+        if torch.all(dones[0:2]):
+            next_obs, info = vec.reset()
+            n_done += 1
+        obs = torch.FloatTensor(next_obs[OBS_KEY]).to(dev)
+    assert n_done == 2
