@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarl_amd.so")
+LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "libmarl_amd.so")  # override: diagnostic builds
 
 EXPORTS = (
     "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_obs_dim", "marl_env_num_rows",

@@ -16,17 +16,17 @@
 
 namespace oc {
 template <int A>
-hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint8_t* tab, uint32_t* state,
-                               const void* actions, int act_size, const uint8_t* prio, const uint8_t* spawn_ov,
+hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint8_t* tab, const uint8_t* aux,
+                               uint32_t* state, const void* actions, int act_size, const uint8_t* prio, const uint8_t* spawn_ov,
                                const uint8_t* dir_ov, float* obs, float* rewards, uint8_t* term, uint8_t* trunc,
                                int mode, hipStream_t stream);
-extern template hipError_t launch_env_kernel_A<1>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+extern template hipError_t launch_env_kernel_A<1>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
                                                   const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
                                                   uint8_t*, int, hipStream_t);
-extern template hipError_t launch_env_kernel_A<2>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+extern template hipError_t launch_env_kernel_A<2>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
                                                   const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
                                                   uint8_t*, int, hipStream_t);
-extern template hipError_t launch_env_kernel_A<4>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*, int,
+extern template hipError_t launch_env_kernel_A<4>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
                                                   const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
                                                   uint8_t*, int, hipStream_t);
 hipError_t launch_gae(const float* rewards, const float* dones, const float* values, const float* next_values,
@@ -50,8 +50,10 @@ static int fail_hip(hipError_t e, const char* what) {
 struct marl_env {
     EnvParams P;
     int A, feat, niw, H, W, ncell, NP, D, BLK, words;
-    std::vector<uint8_t> tab;  // host copy of the lookup blob
+    std::vector<uint8_t> tab;  // host copy of the hot lookup blob
+    std::vector<uint8_t> aux;  // host copy of the cell-indexed tables of the snapshot kernels
     uint8_t* d_tab;
+    uint8_t* d_aux;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -68,18 +70,22 @@ static int dist_of(int metric, int dy, int dx) {
     return metric ? dy * dy + dx * dx : std::abs(dy) + std::abs(dx);
 }
 
+static bool by_distance(const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; }
+
 // (agent - object) for the n nearest cells of one static type; stable on ties => scan order
 static void static_closest(const std::vector<uint8_t>& type, int W, int ncell, uint32_t kind, int n, int ar, int ac,
                            int metric, int8_t* out) {
     std::vector<std::pair<int, int>> cand;  // (distance, cell)
     for (int c = 0; c < ncell; ++c)
         if (type[c] == kind) cand.push_back({dist_of(metric, ar - c / W, ac - c % W), c});
-    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    std::stable_sort(cand.begin(), cand.end(), by_distance);
     for (int k = 0; k < n && k < (int)cand.size(); ++k) {
         out[2 * k] = (int8_t)(ar - cand[k].second / W);
         out[2 * k + 1] = (int8_t)(ac - cand[k].second % W);
     }
 }
+
+static int align16(int x) { return (x + 15) & ~15; }
 
 static int build_tables(marl_env* env, const char* const* rows, int height, int dist_metric) {
     const int H = height;
@@ -112,49 +118,69 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
         }
     }
     const int A = env->A;
-    if ((int)pot_cells.size() > MAX_POTS) return fail(MARL_ERR_LAYOUT, "more than 8 pots");
+    if ((int)pot_cells.size() > MAX_POTS) return fail(MARL_ERR_LAYOUT, "more than 4 pots");
     if ((int)floor_cells.size() < A) return fail(MARL_ERR_LAYOUT, "fewer floor cells than agents");
     if (!spawn.empty() && (int)spawn.size() < A) return fail(MARL_ERR_LAYOUT, "fewer '+' spawn cells than agents");
-    if ((int)slots.size() > 128) return fail(MARL_ERR_LAYOUT, "more than 128 item-capable cells");
+    if ((int)slots.size() > MAX_SLOTS) return fail(MARL_ERR_LAYOUT, "more than 126 item-capable cells");
 
-    env->H = H; env->W = W; env->ncell = ncell; env->NP = (int)pot_cells.size();
+    const int nfloor = (int)floor_cells.size(), nslots = (int)slots.size(), NP = (int)pot_cells.size();
+    env->H = H; env->W = W; env->ncell = ncell; env->NP = NP;
     env->BLK = block_dim(A, env->feat);
     env->D = env->feat == FEAT_GLOBAL ? A * env->BLK : env->BLK;
-    const int NW = (env->BLK + 3) / 4;
-    env->niw = item_words_padded((int)slots.size());
-    env->words = state_words(A, env->NP, (int)slots.size());
+    const int NW = (env->BLK + 3) / 4, NWP = (NW + 3) / 4 * 4;
+    env->niw = item_words_padded(nslots);
+    env->words = state_words(A, nslots);
 
-    const int nfloor = (int)floor_cells.size();
-    size_t bytes = TAB_POSTAB + (size_t)nfloor * NW * 4;
-    bytes = (bytes + 15) & ~(size_t)15;
-    env->tab.assign(bytes, 0);
+    // cell-indexed helper tables (also the aux blob of the snapshot kernels)
+    env->aux.assign(AUX_BYTES, 0xFF);
+    uint8_t* aux = env->aux.data();
+    for (int k = 0; k < nfloor; ++k) { aux[AUX_FLOOR_CELL + k] = (uint8_t)floor_cells[k]; aux[AUX_FIDX_OF_CELL + floor_cells[k]] = (uint8_t)k; }
+    for (int k = 0; k < nslots; ++k) { aux[AUX_CELL_OF_SLOT + k] = (uint8_t)slots[k]; aux[AUX_SLOT_OF_CELL + slots[k]] = (uint8_t)k; }
+    std::vector<int> pot_of_cell(ncell, -1);
+    for (int k = 0; k < NP; ++k) pot_of_cell[pot_cells[k]] = k;
+
+    EnvParams& P = env->P;
+    P.NP = NP; P.nslots = nslots; P.nfloor = nfloor; P.nspawn = (int)spawn.size(); P.dist_metric = dist_metric;
+    int off = 0;
+    P.off_nb = off; off = align16(off + nfloor * 16);
+    P.off_postab = off; off = align16(off + nfloor * NWP * 4);
+    P.off_frc = off; off = align16(off + nfloor * 2);
+    P.off_slotrc = off; off = align16(off + 128 * 2);  // full size: the "no slot" code may be looked up (result unused)
+    P.off_potorder = off; off = align16(off + nfloor * 2);
+    P.off_spawnf = off; off = align16(off + (int)spawn.size() + 1);
+    P.tab_bytes = off;
+    env->tab.assign((size_t)off, 0);
     uint8_t* t = env->tab.data();
-    memset(t + TAB_SLOT_OF_CELL, 0xFF, 256);
-    memset(t + TAB_POT_OF_CELL, 0xFF, 256);
-    memset(t + TAB_FIDX_OF_CELL, 0, 256);
-    memset(t + TAB_POT_ORDER, 0xFF, 512);
-    for (int c = 0; c < ncell; ++c) {
-        t[TAB_CELLTYPE + c] = type[c];
-        reinterpret_cast<uint16_t*>(t + TAB_CELL_RC)[c] = (uint16_t)(((c / W) << 8) | (c % W));
-    }
-    for (int k = 0; k < (int)slots.size(); ++k) { t[TAB_SLOT_OF_CELL + slots[k]] = (uint8_t)k; t[TAB_CELL_OF_SLOT + k] = (uint8_t)slots[k]; }
-    for (int k = 0; k < (int)pot_cells.size(); ++k) { t[TAB_POT_OF_CELL + pot_cells[k]] = (uint8_t)k; t[TAB_POT_CELL + k] = (uint8_t)pot_cells[k]; }
-    for (int k = 0; k < nfloor; ++k) { t[TAB_FIDX_OF_CELL + floor_cells[k]] = (uint8_t)k; t[TAB_FLOOR_CELL + k] = (uint8_t)floor_cells[k]; }
-    for (int k = 0; k < (int)spawn.size(); ++k) t[TAB_SPAWN_CELL + k] = (uint8_t)spawn[k];
+
+    uint32_t* nb = reinterpret_cast<uint32_t*>(t + P.off_nb);
+    uint16_t* frc = reinterpret_cast<uint16_t*>(t + P.off_frc);
+    uint16_t* slotrc = reinterpret_cast<uint16_t*>(t + P.off_slotrc);
+    for (int k = 0; k < nslots; ++k) slotrc[k] = (uint16_t)(((slots[k] / W) << 8) | (slots[k] % W));
+    for (int k = 0; k < (int)spawn.size(); ++k) t[P.off_spawnf + k] = aux[AUX_FIDX_OF_CELL + spawn[k]];
+    memset(t + P.off_potorder, 0xFF, (size_t)nfloor * 2);
 
     const bool full = env->feat == FEAT_GLOBAL || env->feat == FEAT_LOCAL;
     const bool others = full || env->feat == FEAT_MINIMAL_OTHER;
     const bool spatial = env->feat != FEAT_ONLY_DIRECTION;
     const int o_pos = (full ? 93 : 27) + (others ? 2 * (A - 1) : 0);
+    static const int dir_dr[4] = {0, 1, 0, -1}, dir_dc[4] = {1, 0, -1, 0};  // right, down, left, up
     static const int adj_dr[4] = {0, 0, 1, -1}, adj_dc[4] = {1, -1, 0, 0};  // right, left, down, up
     for (int k = 0; k < nfloor; ++k) {
         const int cell = floor_cells[k], ar = cell / W, ac = cell % W;
-        int8_t* blk = reinterpret_cast<int8_t*>(t + TAB_POSTAB) + (size_t)k * NW * 4;
+        frc[k] = (uint16_t)((ar << 8) | ac);
+        for (int d = 0; d < 4; ++d) {
+            const int c = (ar + dir_dr[d]) * W + ac + dir_dc[d];
+            const uint32_t slot = aux[AUX_SLOT_OF_CELL + c] == 0xFF ? NB_NO_SLOT : aux[AUX_SLOT_OF_CELL + c];
+            const uint32_t pot = pot_of_cell[c] < 0 ? NB_NO_POT : (uint32_t)pot_of_cell[c];
+            const uint32_t fi = type[c] == FLOOR ? aux[AUX_FIDX_OF_CELL + c] : 0u;
+            nb[4 * k + d] = nb_pack(type[c], slot, pot, fi);
+        }
+        int8_t* blk = reinterpret_cast<int8_t*>(t + P.off_postab) + (size_t)k * NWP * 4;
         // nearest pots, used by the kernel for the dynamic pot fields as well
         std::vector<std::pair<int, int>> pots;  // (distance, pot id)
-        for (int p = 0; p < env->NP; ++p) pots.push_back({dist_of(dist_metric, ar - pot_cells[p] / W, ac - pot_cells[p] % W), p});
-        std::stable_sort(pots.begin(), pots.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
-        for (int j = 0; j < 2 && j < env->NP; ++j) t[TAB_POT_ORDER + 2 * cell + j] = (uint8_t)pots[j].second;
+        for (int p = 0; p < NP; ++p) pots.push_back({dist_of(dist_metric, ar - pot_cells[p] / W, ac - pot_cells[p] % W), p});
+        std::stable_sort(pots.begin(), pots.end(), by_distance);
+        for (int j = 0; j < 2 && j < NP; ++j) t[P.off_potorder + 2 * k + j] = (uint8_t)pots[j].second;
         if (!spatial) continue;
         for (int j = 0; j < 4; ++j)
             if (type[(ar + adj_dr[j]) * W + ac + adj_dc[j]] == COUNTER) blk[7 + j] = 1;
@@ -163,7 +189,7 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
             static_closest(type, W, ncell, ONION_STACK, 2, ar, ac, dist_metric, blk + 47);
             static_closest(type, W, ncell, DELIVERY, 2, ar, ac, dist_metric, blk + 59);
             static_closest(type, W, ncell, COUNTER, 4, ar, ac, dist_metric, blk + 63);
-            for (int j = 0; j < 2 && j < env->NP; ++j) {
+            for (int j = 0; j < 2 && j < NP; ++j) {
                 const int pc = pot_cells[pots[j].second];
                 int8_t* q = blk + 71 + 11 * j;
                 q[0] = 1;  // "reachable", a constant in the feature this stands in for
@@ -173,17 +199,13 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
         }
         blk[o_pos] = (int8_t)ar; blk[o_pos + 1] = (int8_t)ac;
     }
-
-    EnvParams& P = env->P;
-    P.W = W; P.NP = env->NP; P.nslots = (int)slots.size(); P.nfloor = nfloor; P.nspawn = (int)spawn.size();
-    P.tab_bytes = (int)bytes; P.dist_metric = dist_metric;
     return MARL_OK;
 }
 
 // ---------------------------------------------------------------------------------------
 // snapshot kernels (one thread per env; setup / test path, not the hot path)
 // ---------------------------------------------------------------------------------------
-__global__ void export_kernel(EnvParams P, int A, int niw, int ncell, const uint8_t* __restrict__ tab,
+__global__ void export_kernel(EnvParams P, int A, int niw, int ncell, int W, const uint8_t* __restrict__ aux,
                               const uint32_t* __restrict__ st, int32_t* agents, int32_t* pots, uint8_t* items,
                               int32_t* misc) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,32 +214,30 @@ __global__ void export_kernel(EnvParams P, int A, int niw, int ncell, const uint
     int w = 0;
     misc[2 * e] = (int32_t)(st[(w++) * E + e] & 0xFFFFu);
     misc[2 * e + 1] = (int32_t)st[(w++) * E + e];
-    uint64_t pw = st[(w++) * E + e];
-    if (P.NP > 4) pw |= (uint64_t)st[(w++) * E + e] << 32;
+    const uint32_t pw = st[(w++) * E + e];
     for (int p = 0; p < P.NP; ++p) {
         pots[((size_t)e * P.NP + p) * 2] = (int32_t)((pw >> (8 * p)) & 3u);
         pots[((size_t)e * P.NP + p) * 2 + 1] = (int32_t)((pw >> (8 * p + 2)) & 31u);
     }
-    const uint16_t* rc = reinterpret_cast<const uint16_t*>(tab + TAB_CELL_RC);
     for (int k = 0; k < (A + 1) / 2; ++k) {
         const uint32_t aw = st[(w++) * E + e];
         for (int h = 0; h < 2 && 2 * k + h < A; ++h) {
             const uint32_t v = aw >> (16 * h);
             int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
-            const uint32_t cell = v & 0xFFu;
-            o[0] = rc[cell] >> 8; o[1] = rc[cell] & 0xFF; o[2] = (v >> 8) & 3u; o[3] = (v >> 10) & 3u;
+            const uint32_t cell = aux[AUX_FLOOR_CELL + (v & 0xFFu)];
+            o[0] = (int32_t)(cell / W); o[1] = (int32_t)(cell % W); o[2] = (v >> 8) & 3u; o[3] = (v >> 10) & 3u;
         }
     }
     for (int c = 0; c < ncell; ++c) {
-        const uint32_t slot = tab[TAB_SLOT_OF_CELL + c];
+        const uint32_t slot = aux[AUX_SLOT_OF_CELL + c];
         uint8_t it = 0;
         if (slot != 0xFFu) it = (uint8_t)((st[(size_t)(w + (slot >> 4)) * E + e] >> ((slot & 15u) * 2u)) & 3u);
         items[(size_t)e * ncell + c] = it;
     }
 }
 
-__global__ void import_kernel(EnvParams P, int A, int niw, int ncell, const uint8_t* __restrict__ tab, uint32_t* st,
-                              const int32_t* __restrict__ agents, const int32_t* __restrict__ pots,
+__global__ void import_kernel(EnvParams P, int A, int niw, int ncell, int W, const uint8_t* __restrict__ aux,
+                              uint32_t* st, const int32_t* __restrict__ agents, const int32_t* __restrict__ pots,
                               const uint8_t* __restrict__ items, const int32_t* __restrict__ misc) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.E) return;
@@ -225,19 +245,19 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, const uint
     int w = 0;
     st[(w++) * E + e] = (uint32_t)misc[2 * e] & 0xFFFFu;
     st[(w++) * E + e] = (uint32_t)misc[2 * e + 1];
-    uint64_t pw = 0;
+    uint32_t pw = 0;
     for (int p = 0; p < P.NP; ++p) {
-        const uint64_t b = ((uint64_t)pots[((size_t)e * P.NP + p) * 2] & 3u) |
-                           (((uint64_t)pots[((size_t)e * P.NP + p) * 2 + 1] & 31u) << 2);
+        const uint32_t b = ((uint32_t)pots[((size_t)e * P.NP + p) * 2] & 3u) |
+                           (((uint32_t)pots[((size_t)e * P.NP + p) * 2 + 1] & 31u) << 2);
         pw |= b << (8 * p);
     }
-    st[(w++) * E + e] = (uint32_t)pw;
-    if (P.NP > 4) st[(w++) * E + e] = (uint32_t)(pw >> 32);
+    st[(w++) * E + e] = pw;
     for (int k = 0; k < (A + 1) / 2; ++k) {
         uint32_t aw = 0;
         for (int h = 0; h < 2 && 2 * k + h < A; ++h) {
             const int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
-            const uint32_t v = (uint32_t)(o[0] * P.W + o[1]) | ((uint32_t)o[2] << 8) | ((uint32_t)o[3] << 10);
+            const uint32_t fi = aux[AUX_FIDX_OF_CELL + (uint32_t)(o[0] * W + o[1])];
+            const uint32_t v = fi | ((uint32_t)o[2] << 8) | ((uint32_t)o[3] << 10);
             aw |= v << (16 * h);
         }
         st[(w++) * E + e] = aw;
@@ -246,7 +266,7 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, const uint
         uint32_t word = 0;
         for (int j = 0; j < 16; ++j) {
             const int slot = k * 16 + j;
-            if (slot < P.nslots) word |= ((uint32_t)items[(size_t)e * ncell + tab[TAB_CELL_OF_SLOT + slot]] & 3u) << (2 * j);
+            if (slot < P.nslots) word |= ((uint32_t)items[(size_t)e * ncell + aux[AUX_CELL_OF_SLOT + slot]] & 3u) << (2 * j);
         }
         st[(size_t)(w + k) * E + e] = word;
     }
@@ -270,7 +290,7 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     if ((int64_t)num_envs * num_agents > 0x7FFFFFFF) return fail(MARL_ERR_INVALID, "num_envs * num_agents exceeds 2^31-1");
     if (dist_metric != 0 && dist_metric != 1) return fail(MARL_ERR_INVALID, "dist_metric must be 0 or 1");
     marl_env* env = new marl_env();
-    env->A = num_agents; env->feat = feature; env->d_tab = nullptr;
+    env->A = num_agents; env->feat = feature; env->d_tab = nullptr; env->d_aux = nullptr;
     int rc = build_tables(env, layout_rows, height, dist_metric);
     if (rc != MARL_OK) { delete env; return rc; }
     EnvParams& P = env->P;
@@ -280,9 +300,15 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     P.env_base_lo = (uint32_t)(uint64_t)env_index_base;
     P.env_base_hi = (uint32_t)((uint64_t)env_index_base >> 32);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&env->d_tab), env->tab.size());
-    if (e != hipSuccess) { delete env; return fail_hip(e, "hipMalloc(lookup tables)"); }
-    e = hipMemcpy(env->d_tab, env->tab.data(), env->tab.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(env->d_tab); delete env; return fail_hip(e, "hipMemcpy(lookup tables)"); }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&env->d_aux), env->aux.size());
+    if (e == hipSuccess) e = hipMemcpy(env->d_tab, env->tab.data(), env->tab.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(env->d_aux, env->aux.data(), env->aux.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (env->d_tab) (void)hipFree(env->d_tab);
+        if (env->d_aux) (void)hipFree(env->d_aux);
+        delete env;
+        return fail_hip(e, "device allocation / upload of the lookup tables");
+    }
     *out = env;
     return MARL_OK;
 }
@@ -290,6 +316,7 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
 extern "C" void marl_env_destroy(marl_env_t* env) {
     if (!env) return;
     if (env->d_tab) (void)hipFree(env->d_tab);
+    if (env->d_aux) (void)hipFree(env->d_aux);
     delete env;
 }
 
@@ -314,9 +341,9 @@ static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, i
     hipError_t e;
     uint32_t* st = reinterpret_cast<uint32_t*>(d_state);
     switch (env->A) {
-        case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
-        case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
-        case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, env->P, env->d_tab, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
         default: return fail(MARL_ERR_INVALID, "unsupported agent count");
     }
     if (e != hipSuccess) return fail_hip(e, "env kernel launch");
@@ -356,7 +383,7 @@ extern "C" int marl_env_export_state(marl_env_t* env, const void* d_state, int32
         return fail(MARL_ERR_INVALID, "NULL argument to marl_env_export_state");
     const int block = 128, grid = (env->P.E + block - 1) / block;
     hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream), env->P, env->A,
-                       env->niw, env->ncell, env->d_tab, reinterpret_cast<const uint32_t*>(d_state), d_agents, d_pots,
+                       env->niw, env->ncell, env->W, env->d_aux, reinterpret_cast<const uint32_t*>(d_state), d_agents, d_pots,
                        d_items, d_misc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MARL_OK : fail_hip(e, "export kernel launch");
@@ -368,7 +395,7 @@ extern "C" int marl_env_import_state(marl_env_t* env, void* d_state, const int32
         return fail(MARL_ERR_INVALID, "NULL argument to marl_env_import_state");
     const int block = 128, grid = (env->P.E + block - 1) / block;
     hipLaunchKernelGGL(import_kernel, dim3(grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream), env->P, env->A,
-                       env->niw, env->ncell, env->d_tab, reinterpret_cast<uint32_t*>(d_state), d_agents, d_pots, d_items,
+                       env->niw, env->ncell, env->W, env->d_aux, reinterpret_cast<uint32_t*>(d_state), d_agents, d_pots, d_items,
                        d_misc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MARL_OK : fail_hip(e, "import kernel launch");

@@ -9,7 +9,11 @@
 // rows in LDS.  Finally the wave streams that image out: one aligned LDS dword (4 features)
 // per lane per iteration -> 4 floats -> one 16-byte store, so every store instruction writes
 // 1 KiB of consecutive HBM bytes.  The float32 observation write is >90 % of the algorithmic
-// bytes of this path; everything else is sized to stay out of its way.
+// bytes of this path, and at 65,536 envs the whole launch is a single round of waves: what
+// the simulation costs is its per-lane LATENCY, which delays the store stream.  Hence the
+// style below: everything an agent needs to know about the cell in front of it comes from ONE
+// 16-byte LDS read (its floor cell's four neighbour words), and the dynamics are written as
+// selects, not branches.
 //
 // Replaces, for the reference's drivers, the third-party env.step()/reset() reached at
 // agent_environment.py:34,50,88 and the feature composition of
@@ -37,6 +41,7 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<B + 1, E>(f);
     }
 }
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
@@ -47,9 +52,10 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 struct Rng {
     uint32_t key;
     uint32_t ctr;
-    __device__ __forceinline__ uint32_t below(uint32_t n) {
-        uint32_t r = mix32(key ^ ctr);
-        ++ctr;
+    // draw in [0, n) if `take`, else leave the counter alone (the value is then unused)
+    __device__ __forceinline__ uint32_t below(uint32_t n, bool take = true) {
+        const uint32_t r = mix32(key ^ ctr);
+        ctr += take ? 1u : 0u;
         return __umulhi(r, n);
     }
 };
@@ -61,14 +67,15 @@ __device__ __forceinline__ uint32_t item_get(const uint32_t (&it)[NIW], uint32_t
     return (w >> ((slot & 15u) * 2u)) & 3u;
 }
 
+// items[slot] = v where `on`; nothing otherwise
 template <int NIW>
-__device__ __forceinline__ void item_set(uint32_t (&it)[NIW], uint32_t slot, uint32_t v) {
+__device__ __forceinline__ void item_set(uint32_t (&it)[NIW], uint32_t slot, uint32_t v, bool on) {
     const uint32_t sh = (slot & 15u) * 2u;
-    const uint32_t keep = ~(3u << sh);
+    const uint32_t field = 3u << sh;
     const uint32_t val = v << sh;
     static_for<0, NIW>([&](auto K) {
-        const uint32_t hit = (slot >> 4) == (uint32_t)K.value ? 0xFFFFFFFFu : 0u;
-        it[K.value] = (it[K.value] & (keep | ~hit)) | (val & hit);
+        const uint32_t m = (on && (slot >> 4) == (uint32_t)K.value) ? field : 0u;
+        it[K.value] = (it[K.value] & ~m) | (val & m);
     });
 }
 
@@ -80,44 +87,39 @@ __device__ __forceinline__ uint32_t pick(const uint32_t (&v)[A], uint32_t i) {
     return r;
 }
 
-__device__ __forceinline__ int dir_delta(uint32_t d, int W) {
-    int s = (d & 1u) ? W : 1;  // right +1, down +W, left -1, up -W
-    return (d & 2u) ? -s : s;
+__device__ __forceinline__ uint32_t sel4(const uint4& v, uint32_t d) {
+    const uint32_t lo = (d & 1u) ? v.y : v.x;
+    const uint32_t hi = (d & 1u) ? v.w : v.z;
+    return (d & 2u) ? hi : lo;
 }
 
-// adjacency enumeration shared by NextToCounter / NextToPot / CanMoveDirection:
-// 0 = right, 1 = left, 2 = down, 3 = up (pinned by the reference's golden vector)
-__device__ __forceinline__ int adj_delta(int k, int W) {
-    return k == 0 ? 1 : k == 1 ? -1 : k == 2 ? W : -W;
-}
+__device__ __forceinline__ uint32_t nb_type(uint32_t w) { return w & 7u; }
+__device__ __forceinline__ uint32_t nb_slot(uint32_t w) { return (w >> 3) & 127u; }
+__device__ __forceinline__ uint32_t nb_pot(uint32_t w) { return (w >> 10) & 3u; }  // meaningful when the type is POT
+__device__ __forceinline__ uint32_t nb_fidx(uint32_t w) { return (w >> 16) & 255u; }
 
-__device__ __forceinline__ uint32_t pot_count(uint64_t pots, uint32_t p) { return (uint32_t)(pots >> (8u * p)) & 3u; }
-__device__ __forceinline__ uint32_t pot_timer(uint64_t pots, uint32_t p) { return (uint32_t)(pots >> (8u * p + 2u)) & 31u; }
-__device__ __forceinline__ uint32_t pot_class(uint64_t pots, uint32_t p) {
+__device__ __forceinline__ uint32_t pot_count(uint32_t pots, uint32_t p) { return (pots >> (8u * p)) & 3u; }
+__device__ __forceinline__ uint32_t pot_timer(uint32_t pots, uint32_t p) { return (pots >> (8u * p + 2u)) & 31u; }
+__device__ __forceinline__ uint32_t pot_class(uint32_t pots, uint32_t p) {
     const uint32_t c = pot_count(pots, p), t = pot_timer(pots, p);
     return c == 0 ? POT_EMPTY : c < (uint32_t)POT_CAPACITY ? POT_PARTIAL : t > 0 ? POT_COOKING : POT_READY;
 }
 
 struct Lds {
     const uint8_t* b;
-    __device__ __forceinline__ uint32_t celltype(uint32_t c) const { return b[TAB_CELLTYPE + c]; }
-    __device__ __forceinline__ uint32_t slot(uint32_t c) const { return b[TAB_SLOT_OF_CELL + c]; }
-    __device__ __forceinline__ uint32_t pot(uint32_t c) const { return b[TAB_POT_OF_CELL + c]; }
-    __device__ __forceinline__ uint32_t fidx(uint32_t c) const { return b[TAB_FIDX_OF_CELL + c]; }
-    __device__ __forceinline__ uint32_t rc(uint32_t c) const {
-        return reinterpret_cast<const uint16_t*>(b + TAB_CELL_RC)[c];
+    const EnvParams& P;
+    __device__ __forceinline__ uint4 nb(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_nb)[f]; }
+    __device__ __forceinline__ uint32_t frc(uint32_t f) const {
+        return reinterpret_cast<const uint16_t*>(b + P.off_frc)[f];
     }
-    __device__ __forceinline__ uint32_t cell_of_slot(uint32_t s) const { return b[TAB_CELL_OF_SLOT + s]; }
-    __device__ __forceinline__ uint32_t floor_cell(uint32_t i) const { return b[TAB_FLOOR_CELL + i]; }
-    __device__ __forceinline__ uint32_t spawn_cell(uint32_t i) const { return b[TAB_SPAWN_CELL + i]; }
-    __device__ __forceinline__ uint32_t pot_order(uint32_t c, int k) const { return b[TAB_POT_ORDER + 2 * c + k]; }
+    __device__ __forceinline__ uint32_t slotrc(uint32_t s) const {
+        return reinterpret_cast<const uint16_t*>(b + P.off_slotrc)[s];
+    }
+    __device__ __forceinline__ uint32_t pot_order(uint32_t f) const {  // two pot ids, low byte = nearest
+        return reinterpret_cast<const uint16_t*>(b + P.off_potorder)[f];
+    }
+    __device__ __forceinline__ uint32_t spawnf(uint32_t i) const { return b[P.off_spawnf + i]; }
 };
-
-// a bare floor tile with nothing lying on it
-template <int NIW>
-__device__ __forceinline__ bool walkable(const Lds& T, const uint32_t (&items)[NIW], uint32_t c) {
-    return T.celltype(c) == FLOOR && item_get<NIW>(items, T.slot(c)) == NONE;
-}
 
 // ---------------------------------------------------------------------------------------
 // env state in registers
@@ -126,75 +128,78 @@ template <int A, int NIW>
 struct EnvState {
     uint32_t t;
     Rng rng;
-    uint64_t pots;
-    uint32_t cell[A], dir[A], inv[A];
+    uint32_t pots;
+    uint32_t f[A], dir[A], inv[A];  // floor index, facing, holding
     uint32_t items[NIW];
 };
 
+constexpr int state_words_ct(int A, int NIW) { return 3 + (A + 1) / 2 + NIW; }
+
 template <int A, int NIW>
-__device__ __forceinline__ void load_state(EnvState<A, NIW>& s, const uint32_t* __restrict__ st, int E, int e, int NP) {
+__device__ __forceinline__ void load_raw(uint32_t (&raw)[3 + (A + 1) / 2 + NIW], const uint32_t* __restrict__ st, int E, int e) {
     const uint32_t* p = st + e;
-    const size_t stride = (size_t)E;
-    s.t = p[0] & 0xFFFFu;
-    s.rng.ctr = p[stride];
-    s.pots = p[2 * stride];
-    const int base = NP > 4 ? 4 : 3;
-    if (NP > 4) s.pots |= (uint64_t)p[3 * stride] << 32;
-    static_for<0, (A + 1) / 2>([&](auto K) {
-        constexpr int k = K.value;
-        const uint32_t aw = p[(size_t)(base + k) * stride];
-        s.cell[2 * k] = aw & 0xFFu; s.dir[2 * k] = (aw >> 8) & 3u; s.inv[2 * k] = (aw >> 10) & 3u;
-        if constexpr (2 * k + 1 < A) {
-            s.cell[2 * k + 1] = (aw >> 16) & 0xFFu; s.dir[2 * k + 1] = (aw >> 24) & 3u; s.inv[2 * k + 1] = (aw >> 26) & 3u;
-        }
-    });
-    static_for<0, NIW>([&](auto K) { s.items[K.value] = p[(size_t)(base + (A + 1) / 2 + K.value) * stride]; });
+    static_for<0, 3 + (A + 1) / 2 + NIW>([&](auto K) { raw[K.value] = p[(size_t)K.value * (size_t)E]; });
 }
 
 template <int A, int NIW>
-__device__ __forceinline__ void store_state(const EnvState<A, NIW>& s, uint32_t* __restrict__ st, int E, int e, int NP) {
+__device__ __forceinline__ void unpack_state(EnvState<A, NIW>& s, const uint32_t (&raw)[3 + (A + 1) / 2 + NIW]) {
+    s.t = raw[0] & 0xFFFFu;
+    s.rng.ctr = raw[1];
+    s.pots = raw[2];
+    static_for<0, (A + 1) / 2>([&](auto K) {
+        constexpr int k = K.value;
+        const uint32_t aw = raw[3 + k];
+        s.f[2 * k] = aw & 0xFFu; s.dir[2 * k] = (aw >> 8) & 3u; s.inv[2 * k] = (aw >> 10) & 3u;
+        if constexpr (2 * k + 1 < A) {
+            s.f[2 * k + 1] = (aw >> 16) & 0xFFu; s.dir[2 * k + 1] = (aw >> 24) & 3u; s.inv[2 * k + 1] = (aw >> 26) & 3u;
+        }
+    });
+    static_for<0, NIW>([&](auto K) { s.items[K.value] = raw[3 + (A + 1) / 2 + K.value]; });
+}
+
+template <int A, int NIW>
+__device__ __forceinline__ void store_state(const EnvState<A, NIW>& s, uint32_t* __restrict__ st, int E, int e) {
     uint32_t* p = st + e;
     const size_t stride = (size_t)E;
     p[0] = s.t;
     p[stride] = s.rng.ctr;
-    p[2 * stride] = (uint32_t)s.pots;
-    const int base = NP > 4 ? 4 : 3;
-    if (NP > 4) p[3 * stride] = (uint32_t)(s.pots >> 32);
+    p[2 * stride] = s.pots;
     static_for<0, (A + 1) / 2>([&](auto K) {
         constexpr int k = K.value;
-        uint32_t aw = s.cell[2 * k] | (s.dir[2 * k] << 8) | (s.inv[2 * k] << 10);
-        if constexpr (2 * k + 1 < A) aw |= (s.cell[2 * k + 1] << 16) | (s.dir[2 * k + 1] << 24) | (s.inv[2 * k + 1] << 26);
-        p[(size_t)(base + k) * stride] = aw;
+        uint32_t aw = s.f[2 * k] | (s.dir[2 * k] << 8) | (s.inv[2 * k] << 10);
+        if constexpr (2 * k + 1 < A) aw |= (s.f[2 * k + 1] << 16) | (s.dir[2 * k + 1] << 24) | (s.inv[2 * k + 1] << 26);
+        p[(size_t)(3 + k) * stride] = aw;
     });
-    static_for<0, NIW>([&](auto K) { p[(size_t)(base + (A + 1) / 2 + K.value) * stride] = s.items[K.value]; });
+    static_for<0, NIW>([&](auto K) { p[(size_t)(3 + (A + 1) / 2 + K.value) * stride] = s.items[K.value]; });
 }
 
 // ---------------------------------------------------------------------------------------
 // reset: empty kitchen, agents on random free floor cells (or on the '+' cells when the
-// layout has them), random facing.  Draws come from the counter RNG unless overridden.
+// layout has them), random facing.  Draws come from the counter RNG unless overridden
+// (spawn_ov names cells; the cell -> floor index table is read from global memory, rare path).
 // ---------------------------------------------------------------------------------------
 template <int A, int NIW>
 __device__ __forceinline__ void reset_env(EnvState<A, NIW>& s, const Lds& T, const EnvParams& P,
-                                          const uint8_t* spawn_ov, const uint8_t* dir_ov, int e) {
+                                          const uint8_t* spawn_ov, const uint8_t* dir_ov, const uint8_t* aux_g, int e) {
     s.t = 0;
     static_for<0, NIW>([&](auto K) { s.items[K.value] = 0; });
     s.pots = 0;
-    for (int p = 0; p < P.NP; ++p) s.pots |= (uint64_t)(COOK_TIME << 2) << (8 * p);
-    // indices (into the spawn or floor list) already handed out, kept sorted ascending
+    for (int p = 0; p < P.NP; ++p) s.pots |= (uint32_t)(COOK_TIME << 2) << (8 * p);
+    // indices (into the spawn list or the floor list) already handed out, kept sorted ascending
     uint32_t taken[A];
     static_for<0, A>([&](auto K) { taken[K.value] = 0xFFFFFFFFu; });
     static_for<0, A>([&](auto AI) {
         constexpr int a = AI.value;
-        uint32_t c;
+        uint32_t fi;
         if (spawn_ov) {
-            c = spawn_ov[(size_t)e * A + a];
+            fi = aux_g[AUX_FIDX_OF_CELL + spawn_ov[(size_t)e * A + a]];  // overrides name cells
         } else {
             const bool use_spawn = P.nspawn > 0;
             const uint32_t n = (use_spawn ? P.nspawn : P.nfloor) - a;
             uint32_t idx = s.rng.below(n);
             // idx-th entry of the list once the taken ones are skipped
             static_for<0, a>([&](auto B) { idx += (taken[B.value] <= idx) ? 1u : 0u; });
-            c = use_spawn ? T.spawn_cell(idx) : T.floor_cell(idx);
+            fi = use_spawn ? T.spawnf(idx) : idx;
             // insert idx, keeping taken[0..a] sorted
             uint32_t x = idx;
             static_for<0, a + 1>([&](auto B) {
@@ -202,7 +207,7 @@ __device__ __forceinline__ void reset_env(EnvState<A, NIW>& s, const Lds& T, con
                 taken[B.value] = lo; x = hi;
             });
         }
-        s.cell[a] = c;
+        s.f[a] = fi;
         s.dir[a] = dir_ov ? (uint32_t)dir_ov[(size_t)e * A + a] : s.rng.below(4);
         s.inv[a] = NONE;
     });
@@ -215,16 +220,21 @@ template <int A, int NIW>
 __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, const EnvParams& P,
                                          const uint32_t (&act)[A], const uint8_t* prio, int e,
                                          uint32_t& onion_mask, uint32_t& dish_mask, uint32_t& deliver_mask) {
-    const int W = P.W;
+    // the four neighbour words of every agent's cell: all the map knowledge this step needs
+    uint4 nb[A];
+    static_for<0, A>([&](auto K) { nb[K.value] = T.nb(s.f[K.value]); });
+
     // what the reward functions look at: holdings and pots BEFORE this step
     uint32_t prev_inv[A];
     static_for<0, A>([&](auto K) { prev_inv[K.value] = s.inv[K.value]; });
-    const uint64_t prev_pots = s.pots;
+    const uint32_t prev_pots = s.pots;
 
     s.t += 1;
     // pots that are full keep cooking
-    for (int p = 0; p < P.NP; ++p)
-        if (pot_count(s.pots, p) == POT_CAPACITY && pot_timer(s.pots, p) > 0) s.pots -= (uint64_t)4 << (8 * p);
+    for (int p = 0; p < P.NP; ++p) {
+        const bool cooking = pot_count(s.pots, p) == (uint32_t)POT_CAPACITY && pot_timer(s.pots, p) > 0;
+        s.pots -= cooking ? (4u << (8u * p)) : 0u;
+    }
 
     // ---- movement ----
     uint32_t want[A], npos[A];
@@ -233,67 +243,64 @@ __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, cons
     uint32_t decided = 0;
     static_for<0, A>([&](auto AI) {
         constexpr int a = AI.value;
-        want[a] = s.cell[a];
-        if (act[a] < 4u) {
-            const uint32_t d = (0x0213u >> (4u * act[a])) & 3u;  // up,down,left,right -> 3,1,2,0
-            s.dir[a] = d;  // a move action always turns the agent
-            const uint32_t f = (uint32_t)((int)s.cell[a] + dir_delta(d, W));
-            if (walkable<NIW>(T, s.items, f)) want[a] = f;
-        }
-        npos[a] = s.cell[a];
-        if (want[a] == s.cell[a]) {
-            decided |= 1u << a;  // stayers keep their cell unconditionally
-        } else {
-            movers |= (uint32_t)a << (4u * m);
-            ++m;
-        }
+        const bool is_move = act[a] < 4u;
+        const uint32_t d = (0x0213u >> (4u * (act[a] & 3u))) & 3u;  // up,down,left,right -> 3,1,2,0
+        s.dir[a] = is_move ? d : s.dir[a];                           // a move action always turns the agent
+        const uint32_t w = sel4(nb[a], d);
+        const bool open = nb_type(w) == FLOOR && item_get<NIW>(s.items, nb_slot(w)) == NONE;
+        want[a] = (is_move && open) ? nb_fidx(w) : s.f[a];
+        npos[a] = s.f[a];
+        const bool stays = want[a] == s.f[a];
+        decided |= stays ? (1u << a) : 0u;  // stayers keep their cell unconditionally
+        movers |= stays ? 0u : ((uint32_t)a << (4u * m));
+        m += stays ? 0u : 1u;
     });
-    if (prio) {
-        // replay mode: serve movers by ascending (rank, id)
-        uint32_t sorted = 0, left = 0;
-        static_for<0, A>([&](auto K) { if ((uint32_t)K.value < m) left |= 1u << ((movers >> (4 * K.value)) & 15u); });
-        static_for<0, A>([&](auto K) {
-            if ((uint32_t)K.value < m) {
-                uint32_t best = 0xFFFFFFFFu;
-                static_for<0, A>([&](auto AI) {
-                    if (left & (1u << AI.value))
-                        best = min(best, ((uint32_t)prio[(size_t)e * A + AI.value] << 4) | (uint32_t)AI.value);
-                });
-                sorted |= (best & 15u) << (4 * K.value);
-                left &= ~(1u << (best & 15u));
-            }
-        });
-        movers = sorted;
-    } else {
-        // Fisher-Yates on the packed list, i = m-1 .. 1
-        static_for<1, A>([&](auto K) {
-            constexpr int i = A - K.value;  // A-1 .. 1
-            if ((uint32_t)i < m) {
-                const uint32_t j = s.rng.below(i + 1);
-                const uint32_t x = ((movers >> (4 * i)) ^ (movers >> (4 * j))) & 15u;
+    if constexpr (A > 1) {
+        if (prio) {
+            // replay mode: serve movers by ascending (rank, id)
+            uint32_t sorted = 0, left = 0;
+            static_for<0, A>([&](auto K) { if ((uint32_t)K.value < m) left |= 1u << ((movers >> (4 * K.value)) & 15u); });
+            static_for<0, A>([&](auto K) {
+                if ((uint32_t)K.value < m) {
+                    uint32_t best = 0xFFFFFFFFu;
+                    static_for<0, A>([&](auto AI) {
+                        if (left & (1u << AI.value))
+                            best = min(best, ((uint32_t)prio[(size_t)e * A + AI.value] << 4) | (uint32_t)AI.value);
+                    });
+                    sorted |= (best & 15u) << (4 * K.value);
+                    left &= ~(1u << (best & 15u));
+                }
+            });
+            movers = sorted;
+        } else {
+            // Fisher-Yates on the packed list, i = m-1 .. 1
+            static_for<1, A>([&](auto K) {
+                constexpr int i = A - K.value;  // A-1 .. 1
+                const bool on = (uint32_t)i < m;
+                const uint32_t j = s.rng.below(i + 1, on);
+                const uint32_t x = on ? (((movers >> (4 * i)) ^ (movers >> (4 * j))) & 15u) : 0u;
                 movers ^= (x << (4 * i)) | (x << (4 * j));
-            }
-        });
+            });
+        }
     }
     static_for<0, A>([&](auto K) {
-        if ((uint32_t)K.value < m) {
-            const uint32_t a = (movers >> (4 * K.value)) & 15u;
-            const uint32_t wa = pick<A>(want, a);
-            bool taken = false;
-            static_for<0, A>([&](auto B) { taken |= ((decided >> B.value) & 1u) && npos[B.value] == wa; });
-            static_for<0, A>([&](auto B) {
-                npos[B.value] = (a == (uint32_t)B.value && !taken) ? wa : npos[B.value];
-            });
-            decided |= 1u << a;
-        }
+        const bool on = (uint32_t)K.value < m;
+        const uint32_t a = (movers >> (4 * K.value)) & 15u;
+        const uint32_t wa = pick<A>(want, a);
+        bool taken = false;
+        static_for<0, A>([&](auto B) { taken |= ((decided >> B.value) & 1u) && npos[B.value] == wa; });
+        static_for<0, A>([&](auto B) {
+            npos[B.value] = (on && a == (uint32_t)B.value && !taken) ? wa : npos[B.value];
+        });
+        decided |= on ? (1u << a) : 0u;
     });
     // no passing through each other
     static_for<0, A>([&](auto AI) {
         static_for<AI.value + 1, A>([&](auto BI) {
             constexpr int a = AI.value, b = BI.value;
-            if (npos[a] == s.cell[b] && npos[b] == s.cell[a] && npos[a] != s.cell[a]) {
-                npos[a] = s.cell[a]; npos[b] = s.cell[b];
-            }
+            const bool swap = npos[a] == s.f[b] && npos[b] == s.f[a] && npos[a] != s.f[a];
+            npos[a] = swap ? s.f[a] : npos[a];
+            npos[b] = swap ? s.f[b] : npos[b];
         });
     });
     // three or more agents: whoever moved onto a cell somebody was left standing on goes back
@@ -303,56 +310,59 @@ __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, cons
                 constexpr int a = AI.value;
                 bool clash = false;
                 static_for<0, A>([&](auto BI) { if (BI.value != a) clash |= npos[BI.value] == npos[a]; });
-                if (clash && npos[a] != s.cell[a]) npos[a] = s.cell[a];
+                npos[a] = (clash && npos[a] != s.f[a]) ? s.f[a] : npos[a];
             });
         });
     }
-    static_for<0, A>([&](auto K) { s.cell[K.value] = npos[K.value]; });
+    static_for<0, A>([&](auto K) { s.f[K.value] = npos[K.value]; });
 
     // ---- interact (agent-id order) and reward conditions (previous state) ----
+    // A PickupDrop agent neither moved nor turned, so the neighbour words loaded above are
+    // still those of its cell and its front cell is also its previous front cell.
     onion_mask = dish_mask = deliver_mask = 0;
     static_for<0, A>([&](auto AI) {
         constexpr int a = AI.value;
-        if (act[a] == ACT_PICKUP_DROP) {
-            const uint32_t f = (uint32_t)((int)s.cell[a] + dir_delta(s.dir[a], W));
-            const uint32_t ct = T.celltype(f);
-            const uint32_t slot = T.slot(f);
-            const bool holds_items = (ct == FLOOR || ct == COUNTER);
-            const uint32_t lying = holds_items ? item_get<NIW>(s.items, slot) : (uint32_t)NONE;
-            const uint32_t p = T.pot(f);
-            // a PickupDrop agent neither moved nor turned, so f is also its previous front cell
-            if (ct == POT) {
-                if (prev_inv[a] == ONION && pot_count(prev_pots, p) < (uint32_t)POT_CAPACITY) onion_mask |= 1u << a;
-                if (prev_inv[a] == PLATE && pot_count(prev_pots, p) == (uint32_t)POT_CAPACITY && pot_timer(prev_pots, p) == 0)
-                    dish_mask |= 1u << a;
-            }
-            if (ct == DELIVERY && prev_inv[a] == SOUP) deliver_mask |= 1u << a;
+        const bool on = act[a] == ACT_PICKUP_DROP;
+        const uint32_t w = sel4(nb[a], s.dir[a]);
+        const uint32_t ct = nb_type(w), slot = nb_slot(w), p = nb_pot(w), nf = nb_fidx(w);
+        const bool holds_items = (ct == FLOOR || ct == COUNTER);
+        const uint32_t lying = holds_items ? item_get<NIW>(s.items, slot) : (uint32_t)NONE;
+        const bool is_pot = ct == POT;
 
-            bool ahead = false;
-            static_for<0, A>([&](auto BI) { if (BI.value != a) ahead |= s.cell[BI.value] == f; });
+        const uint32_t ppc = pot_count(prev_pots, p), ppt = pot_timer(prev_pots, p);
+        onion_mask |= (on && is_pot && prev_inv[a] == ONION && ppc < (uint32_t)POT_CAPACITY) ? (1u << a) : 0u;
+        dish_mask |= (on && is_pot && prev_inv[a] == PLATE && ppc == (uint32_t)POT_CAPACITY && ppt == 0) ? (1u << a) : 0u;
+        deliver_mask |= (on && ct == DELIVERY && prev_inv[a] == SOUP) ? (1u << a) : 0u;
 
-            const uint32_t inv = s.inv[a];
-            if (holds_items && lying != NONE && inv == NONE) {
-                s.inv[a] = lying; item_set<NIW>(s.items, slot, NONE);
-            } else if (ct == ONION_STACK && inv == NONE) {
-                s.inv[a] = ONION;
-            } else if (ct == PLATE_STACK && inv == NONE) {
-                s.inv[a] = PLATE;
-            } else if (ct == POT && inv == PLATE && pot_count(s.pots, p) == (uint32_t)POT_CAPACITY && pot_timer(s.pots, p) == 0) {
-                s.inv[a] = SOUP;
-                s.pots = (s.pots & ~((uint64_t)0xFF << (8 * p))) | ((uint64_t)(COOK_TIME << 2) << (8 * p));
-            } else if (inv != NONE) {
-                if (ct == FLOOR && lying == NONE) {
-                    if (!ahead) { item_set<NIW>(s.items, slot, inv); s.inv[a] = NONE; }
-                } else if (ct == COUNTER && lying == NONE) {
-                    item_set<NIW>(s.items, slot, inv); s.inv[a] = NONE;
-                } else if (ct == POT && inv == ONION && pot_count(s.pots, p) < (uint32_t)POT_CAPACITY) {
-                    s.pots += (uint64_t)1 << (8 * p); s.inv[a] = NONE;
-                } else if (ct == DELIVERY && inv == SOUP) {
-                    s.inv[a] = NONE;
-                }
-            }
-        }
+        bool ahead = false;
+        static_for<0, A>([&](auto BI) { if (BI.value != a) ahead |= s.f[BI.value] == nf; });
+        ahead = ahead && ct == FLOOR;
+
+        const uint32_t inv = s.inv[a];
+        const uint32_t pc = pot_count(s.pots, p), pt = pot_timer(s.pots, p);
+        const bool empty_hand = inv == NONE;
+        const bool c_pick = on && holds_items && lying != NONE && empty_hand;
+        const bool c_onion = on && ct == ONION_STACK && empty_hand;
+        const bool c_plate = on && ct == PLATE_STACK && empty_hand;
+        const bool c_soup = on && is_pot && inv == PLATE && pc == (uint32_t)POT_CAPACITY && pt == 0;
+        const bool took = c_pick || c_onion || c_plate || c_soup;
+        const bool may_drop = on && !took && !empty_hand;
+        const bool c_dropf = may_drop && ct == FLOOR && lying == NONE && !ahead;
+        const bool c_dropc = may_drop && ct == COUNTER && lying == NONE;
+        const bool c_pot = may_drop && is_pot && inv == ONION && pc < (uint32_t)POT_CAPACITY;
+        const bool c_deliv = may_drop && ct == DELIVERY && inv == SOUP;
+
+        uint32_t ninv = inv;
+        ninv = (c_dropf || c_dropc || c_pot || c_deliv) ? (uint32_t)NONE : ninv;
+        ninv = c_soup ? (uint32_t)SOUP : ninv;
+        ninv = c_plate ? (uint32_t)PLATE : ninv;
+        ninv = c_onion ? (uint32_t)ONION : ninv;
+        ninv = c_pick ? lying : ninv;
+        s.inv[a] = ninv;
+        item_set<NIW>(s.items, slot, c_pick ? (uint32_t)NONE : inv, c_pick || c_dropf || c_dropc);
+        const uint32_t pbyte = 0xFFu << (8u * p);
+        s.pots = c_soup ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
+        s.pots += c_pot ? (1u << (8u * p)) : 0u;
     });
 }
 
@@ -362,19 +372,19 @@ __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, cons
 template <int NW>
 struct Block {
     uint32_t w[NW];
+    // one byte at compile-time offset OFF
     template <int OFF>
     __device__ __forceinline__ void put(int v) {
         static_assert(OFF / 4 < NW, "offset outside block");
         w[OFF / 4] |= ((uint32_t)v & 0xFFu) << ((OFF % 4) * 8);
     }
-    // byte OFF0 + j, j known only at run time, j in [0, RANGE)
-    template <int OFF0, int RANGE>
-    __device__ __forceinline__ void put_dyn(uint32_t j, int v) {
-        const uint32_t off = OFF0 + j;
-        const uint32_t val = ((uint32_t)v & 0xFFu) << ((off & 3u) * 8u);
-        static_for<OFF0 / 4, (OFF0 + RANGE - 1) / 4 + 1>([&](auto K) {
-            w[K.value] |= ((off >> 2) == (uint32_t)K.value) ? val : 0u;
-        });
+    // four bytes (a dword whose byte k lands at OFF + k) at compile-time offset OFF
+    template <int OFF>
+    __device__ __forceinline__ void put4(uint32_t v) {
+        static_assert(OFF / 4 < NW, "offset outside block");
+        constexpr int sh = (OFF % 4) * 8;
+        w[OFF / 4] |= v << sh;
+        if constexpr (sh != 0 && OFF / 4 + 1 < NW) w[OFF / 4 + 1] |= v >> (32 - sh);
     }
 };
 
@@ -391,69 +401,88 @@ struct Top4 {
     }
 };
 
+// Keys are (distance << 23) | (slot << 16) | (dx & 0xFF) << 8 | (dy & 0xFF): ordered by distance,
+// then by slot (= row-major cell order); the low 16 bits are the two feature bytes themselves.
+__device__ __forceinline__ uint32_t key_pair(uint32_t key) { return key != 0xFFFFFFFFu ? (key & 0xFFFFu) : 0u; }
+
 template <int OFF, int NW>
-__device__ __forceinline__ void emit_closest(Block<NW>& blk, const Lds& T, uint32_t key, int ar, int ac) {
-    if (key != 0xFFFFFFFFu) {
-        const uint32_t rc = T.rc(key & 0xFFu);
-        blk.template put<OFF>(ar - (int)(rc >> 8));
-        blk.template put<OFF + 1>(ac - (int)(rc & 0xFFu));
-    }
+__device__ __forceinline__ void emit_top4(Block<NW>& blk, const Top4& t) {
+    blk.template put4<OFF>(key_pair(t.k0) | (key_pair(t.k1) << 16));
+    blk.template put4<OFF + 4>(key_pair(t.k2) | (key_pair(t.k3) << 16));
 }
 
 template <int OFF, int NW>
-__device__ __forceinline__ void emit_pot(Block<NW>& blk, uint32_t p, uint64_t pots) {
-    if (p != 0xFFu) {
-        const uint32_t cls = pot_class(pots, p);
-        blk.template put_dyn<OFF + 1, 4>((POT_STATUS_INDEX_PACKED >> (4 * cls)) & 15u, 1);
-        const uint32_t cnt = pot_count(pots, p);
-        blk.template put<OFF + 5>((int)cnt);
-        blk.template put<OFF + 6>(cnt == (uint32_t)POT_CAPACITY ? (int)pot_timer(pots, p) : -1);
-    }
+__device__ __forceinline__ void emit_pot(Block<NW>& blk, uint32_t p, uint32_t pots) {
+    const bool have = p != 0xFFu;
+    const uint32_t pp = p & 3u;
+    const uint32_t cls = pot_class(pots, pp);
+    const uint32_t cnt = pot_count(pots, pp);
+    const uint32_t onehot = 1u << (8u * ((POT_STATUS_INDEX_PACKED >> (4 * cls)) & 3u));
+    const uint32_t timer = cnt == (uint32_t)POT_CAPACITY ? pot_timer(pots, pp) : 0xFFu;  // -1 when not cooking
+    blk.template put4<OFF + 1>(have ? onehot : 0u);
+    blk.template put4<OFF + 5>(have ? (cnt | (timer << 8)) : 0u);
 }
 
 template <int A, int FEAT, int NIW>
 __device__ __forceinline__ void build_block(Block<FeatGeom<A, FEAT>::NW>& blk, const EnvState<A, NIW>& s,
                                             const Lds& T, const EnvParams& P, uint32_t i) {
     using G = FeatGeom<A, FEAT>;
-    constexpr int NW = G::NW;
-    const uint32_t mycell = pick<A>(s.cell, i);
+    constexpr int NW = G::NW, NWP = G::NWP;
+    const uint32_t myf = pick<A>(s.f, i);
     const uint32_t mydir = pick<A>(s.dir, i);
     const uint32_t myinv = pick<A>(s.inv, i);
 
-    // static part of the block for an agent standing on this floor cell
-    const uint32_t* tmpl = reinterpret_cast<const uint32_t*>(T.b + TAB_POSTAB) + T.fidx(mycell) * NW;
-    static_for<0, NW>([&](auto K) { blk.w[K.value] = tmpl[K.value]; });
+    // static part of the block for an agent standing on this floor cell, 16 bytes at a time
+    const uint4* tmpl = reinterpret_cast<const uint4*>(T.b + P.off_postab) + myf * (NWP / 4);
+    static_for<0, NWP / 4>([&](auto K) {
+        constexpr int k = K.value;
+        const uint4 v = tmpl[k];
+        blk.w[4 * k] = v.x;
+        if constexpr (4 * k + 1 < NW) blk.w[4 * k + 1] = v.y;
+        if constexpr (4 * k + 2 < NW) blk.w[4 * k + 2] = v.z;
+        if constexpr (4 * k + 3 < NW) blk.w[4 * k + 3] = v.w;
+    });
 
-    blk.template put_dyn<G::O_DIR, 4>(mydir, 1);
+    blk.template put4<G::O_DIR>(1u << (8u * mydir));
     if constexpr (G::kSpatial) {
-        if (myinv != NONE) blk.template put_dyn<G::O_INV, 3>((INVENTORY_INDEX_PACKED >> (4 * myinv)) & 15u, 1);
+        blk.template put4<G::O_INV>(myinv != NONE ? 1u << (8u * ((INVENTORY_INDEX_PACKED >> (4 * myinv)) & 3u)) : 0u);
 
-        const uint32_t rc = T.rc(mycell);
+        const uint32_t rc = T.frc(myf);
         const int ar = (int)(rc >> 8), ac = (int)(rc & 0xFFu);
 
-        // NextToPot (4 status rows x 4 adjacency columns) and CanMoveDirection
+        // NextToPot (4 status rows x 4 adjacency columns) and CanMoveDirection; adjacency order
+        // right, left, down, up (pinned by the reference's golden vector) = directions 0, 2, 1, 3
+        const uint4 me = T.nb(myf);
+        uint32_t ntp[4] = {0u, 0u, 0u, 0u};
+        uint32_t can_move = 0;
         static_for<0, 4>([&](auto K) {
             constexpr int k = K.value;
-            const uint32_t nb = (uint32_t)((int)mycell + adj_delta(k, P.W));
-            const uint32_t ct = T.celltype(nb);
-            if (ct == POT) {
-                const uint32_t row = (NEXT_TO_POT_ROW_PACKED >> (4 * pot_class(s.pots, T.pot(nb)))) & 15u;
-                blk.template put_dyn<G::O_NEXT_POT, 16>(row * 4 + k, 1);
-            }
-            if (ct == FLOOR && item_get<NIW>(s.items, T.slot(nb)) == NONE) blk.template put<G::O_CAN_MOVE + k>(1);
+            const uint32_t w = k == 0 ? me.x : k == 1 ? me.z : k == 2 ? me.y : me.w;
+            const uint32_t ct = nb_type(w);
+            const uint32_t row = (NEXT_TO_POT_ROW_PACKED >> (4 * pot_class(s.pots, nb_pot(w)))) & 3u;
+            static_for<0, 4>([&](auto R) { ntp[R.value] |= (ct == POT && row == (uint32_t)R.value) ? (1u << (8 * k)) : 0u; });
+            can_move |= (ct == FLOOR && item_get<NIW>(s.items, nb_slot(w)) == NONE) ? (1u << (8 * k)) : 0u;
         });
+        blk.template put4<G::O_NEXT_POT + 0>(ntp[0]);
+        blk.template put4<G::O_NEXT_POT + 4>(ntp[1]);
+        blk.template put4<G::O_NEXT_POT + 8>(ntp[2]);
+        blk.template put4<G::O_NEXT_POT + 12>(ntp[3]);
+        blk.template put4<G::O_CAN_MOVE>(can_move);
 
         if constexpr (G::kOthers && A > 1) {
-            // (self - other) for the other agents in id order
+            // (self - other) for the other agents in id order: pair j sits at byte 2j
+            uint32_t lo = 0, hi = 0;
             static_for<0, A>([&](auto BI) {
-                constexpr int b = BI.value;
-                if ((uint32_t)b != i) {
-                    const uint32_t j = (uint32_t)b < i ? (uint32_t)b : (uint32_t)b - 1u;
-                    const uint32_t orc = T.rc(s.cell[b]);
-                    blk.template put_dyn<G::O_OTHERS, 2 * (A - 1)>(2 * j, ar - (int)(orc >> 8));
-                    blk.template put_dyn<G::O_OTHERS, 2 * (A - 1)>(2 * j + 1, ac - (int)(orc & 0xFFu));
-                }
+                constexpr uint32_t b = BI.value;
+                const uint32_t orc = T.frc(s.f[b]);
+                const uint32_t pair = ((uint32_t)(ar - (int)(orc >> 8)) & 0xFFu) | (((uint32_t)(ac - (int)(orc & 0xFFu)) & 0xFFu) << 8);
+                const uint32_t j = b < i ? b : b - 1u;  // unused when b == i
+                const bool other = b != i;
+                lo |= (other && j == 0u) ? pair : (other && j == 1u) ? (pair << 16) : 0u;
+                hi |= (other && j == 2u) ? pair : 0u;
             });
+            blk.template put4<G::O_OTHERS>(lo);
+            if constexpr (A > 3) blk.template put4<G::O_OTHERS + 4>(hi);
         }
 
         if constexpr (G::kFull) {
@@ -468,152 +497,142 @@ __device__ __forceinline__ void build_block(Block<FeatGeom<A, FEAT>::NW>& blk, c
                     const uint32_t bit = __builtin_ctz(nz);
                     nz &= nz - 1;
                     const uint32_t kind = (word >> bit) & 3u;
-                    const uint32_t c = T.cell_of_slot(K.value * 16 + (bit >> 1));
-                    const uint32_t orc = T.rc(c);
+                    const uint32_t slot = K.value * 16 + (bit >> 1);
+                    const uint32_t orc = T.slotrc(slot);
                     const int dy = ar - (int)(orc >> 8), dx = ac - (int)(orc & 0xFFu);
                     const uint32_t d = P.dist_metric ? (uint32_t)(dy * dy + dx * dx) : (uint32_t)(abs(dy) + abs(dx));
-                    const uint32_t key = (d << 8) | c;
+                    const uint32_t key = (d << 23) | (slot << 16) | (((uint32_t)dx & 0xFFu) << 8) | ((uint32_t)dy & 0xFFu);
                     onion.insert(kind == ONION ? key : 0xFFFFFFFFu);
                     plate.insert(kind == PLATE ? key : 0xFFFFFFFFu);
                     soup.insert(kind == SOUP ? key : 0xFFFFFFFFu);
                 }
             });
-            emit_closest<G::O_ONION + 0>(blk, T, onion.k0, ar, ac);
-            emit_closest<G::O_ONION + 2>(blk, T, onion.k1, ar, ac);
-            emit_closest<G::O_ONION + 4>(blk, T, onion.k2, ar, ac);
-            emit_closest<G::O_ONION + 6>(blk, T, onion.k3, ar, ac);
-            emit_closest<G::O_PLATE + 0>(blk, T, plate.k0, ar, ac);
-            emit_closest<G::O_PLATE + 2>(blk, T, plate.k1, ar, ac);
-            emit_closest<G::O_PLATE + 4>(blk, T, plate.k2, ar, ac);
-            emit_closest<G::O_PLATE + 6>(blk, T, plate.k3, ar, ac);
-            emit_closest<G::O_SOUP + 0>(blk, T, soup.k0, ar, ac);
-            emit_closest<G::O_SOUP + 2>(blk, T, soup.k1, ar, ac);
-            emit_closest<G::O_SOUP + 4>(blk, T, soup.k2, ar, ac);
-            emit_closest<G::O_SOUP + 6>(blk, T, soup.k3, ar, ac);
+            emit_top4<G::O_ONION>(blk, onion);
+            emit_top4<G::O_PLATE>(blk, plate);
+            emit_top4<G::O_SOUP>(blk, soup);
 
             // status / contents / timer of the two nearest pots (their static fields are in the template)
-            emit_pot<G::O_POT0>(blk, T.pot_order(mycell, 0), s.pots);
-            emit_pot<G::O_POT1>(blk, T.pot_order(mycell, 1), s.pots);
+            const uint32_t po = T.pot_order(myf);
+            emit_pot<G::O_POT0>(blk, po & 0xFFu, s.pots);
+            emit_pot<G::O_POT1>(blk, po >> 8, s.pots);
         }
     }
 }
 
-// copy a BLK-byte block (NW dwords in registers) to an arbitrary byte address in LDS
+// Copy a BLK-byte block (NW dwords in registers) to an arbitrary byte address in LDS.
+// With sh = distance of dst above the aligned dword BELOW it counted as 1..4 (4 when dst is
+// itself aligned), aligned dword k >= 1 of that frame holds block bytes [4k - sh, 4k - sh + 4):
+// one funnel shift of the register pair (w[k], w[k-1]), the same instruction for every sh.
+// Dwords 1..KFULL lie inside the block for every sh and are stored unconditionally; the few
+// head and tail bytes that some alignment leaves uncovered are stored as single bytes, also
+// unconditionally (a byte written twice gets the same value twice).
 template <int BLK, int NW>
 __device__ __forceinline__ void write_block(uint8_t* img, uint32_t dst, const uint32_t (&w)[NW]) {
-    const uint32_t sh = dst & 3u;
-    uint32_t* base = reinterpret_cast<uint32_t*>(img + (dst - sh));
-    const uint32_t end = sh + BLK;         // first byte past the block, relative to base
-    const uint32_t kt = end >> 2;          // first dword not fully covered
-    const uint32_t tc = end & 3u;          // bytes of the block in dword kt
-    static_for<0, NW + 1>([&](auto K) {
-        constexpr int k = K.value;
-        uint32_t hi = 0u, lo = 0u;
-        if constexpr (k < NW) hi = w[k];
-        if constexpr (k > 0) lo = w[k - 1];
-        // bytes [4k - sh, 4k - sh + 4) of the block: a funnel shift of the register pair
-        const uint32_t v = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - 8u * sh) : hi;
-        uint8_t* bp = reinterpret_cast<uint8_t*>(base + k);
-        if constexpr (k == 0) {
-            if (sh == 0) base[0] = v;
-            else {
-                if (sh <= 1) bp[1] = (uint8_t)(v >> 8);
-                if (sh <= 2) bp[2] = (uint8_t)(v >> 16);
-                bp[3] = (uint8_t)(v >> 24);
-            }
-        } else {
-            if ((uint32_t)k < kt) {
-                base[k] = v;
-            } else if ((uint32_t)k == kt) {
-                if (tc >= 1) bp[0] = (uint8_t)v;
-                if (tc >= 2) bp[1] = (uint8_t)(v >> 8);
-                if (tc >= 3) bp[2] = (uint8_t)(v >> 16);
-            }
-        }
-    });
+    if constexpr (BLK % 4 == 0) {
+        // callers only produce multiples of BLK here: dword copies
+        uint32_t* base = reinterpret_cast<uint32_t*>(img + dst);
+        static_for<0, NW>([&](auto K) { base[K.value] = w[K.value]; });
+    } else {
+        constexpr int KFULL = (BLK + 1) / 4 - 1;
+        static_assert(KFULL >= 1 && KFULL < NW, "block too small for the funnel copy");
+        const uint32_t sh = ((dst + 3u) & 3u) + 1u;
+        uint32_t* base = reinterpret_cast<uint32_t*>(img + (dst - sh));
+        const uint32_t rot = (32u - 8u * sh) & 31u;
+        static_for<1, KFULL + 1>([&](auto K) {
+            constexpr int k = K.value;
+            base[k] = __builtin_amdgcn_alignbit(w[k], w[k - 1], rot);
+        });
+        uint8_t* bp = img + dst;
+        static_for<0, 3>([&](auto J) { bp[J.value] = (uint8_t)(w[0] >> (8 * J.value)); });
+        static_for<4 * KFULL, BLK>([&](auto J) {
+            constexpr int j = J.value;
+            bp[j] = (uint8_t)(w[j / 4] >> (8 * (j % 4)));
+        });
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // the kernel.  mode: 0 = step (+ auto-reset on truncation), 1 = reset every env,
-// 2 = featurize the stored state only.
+// 2 = featurize the stored state only.  Bits 8+ of mode are a profiling aid.
 // ---------------------------------------------------------------------------------------
 template <int A, int FEAT, int NIW>
 __global__ void __launch_bounds__(256)
-env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict__ state,
+env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __restrict__ aux_g,
+           uint32_t* __restrict__ state,
            const void* __restrict__ actions, int act_size, const uint8_t* __restrict__ prio,
            const uint8_t* __restrict__ spawn_ov, const uint8_t* __restrict__ dir_ov,
            float* __restrict__ obs, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
            uint8_t* __restrict__ truncated, int mode) {
     using G = FeatGeom<A, FEAT>;
     constexpr int D = G::D, BLK = G::BLK, NW = G::NW;
+    constexpr int NRAW = 3 + (A + 1) / 2 + NIW;
     extern __shared__ __align__(16) uint8_t smem[];
 
-    // stage the lookup blob
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const size_t N = (size_t)P.E * A;
+    const size_t row0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64;  // first row of this wave
+    const size_t row = row0 + lane;
+    const bool active = row < N;
+    const int e = active ? (int)(row / A) : 0;
+    const uint32_t i = (uint32_t)(row % A);
+    const int ablate = mode >> 8;  // 1 = skip the store stream, 2 = skip the simulation (timing only)
+    mode &= 0xFF;
+
+    // issue the HBM reads first so that they fly while the lookup blob is staged
+    uint32_t raw[NRAW];
+    uint32_t act[A];
+    load_raw<A, NIW>(raw, state, P.E, e);
+    static_for<0, A>([&](auto K) {
+        const size_t r = (size_t)e * A + K.value;
+        act[K.value] = mode != 0    ? (uint32_t)ACT_NOOP
+                     : act_size == 8 ? (uint32_t) reinterpret_cast<const long long*>(actions)[r]
+                     : act_size == 4 ? (uint32_t) reinterpret_cast<const int*>(actions)[r]
+                                     : (uint32_t) reinterpret_cast<const uint8_t*>(actions)[r];
+    });
+
     {
         const uint4* src = reinterpret_cast<const uint4*>(tab_g);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (int k = threadIdx.x; k < P.tab_bytes / 16; k += blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
-    Lds T{smem};
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    Lds T{smem, P};
     uint8_t* img = smem + P.tab_bytes + wave * (64 * D);
 
-    const size_t N = (size_t)P.E * A;
-    const size_t row0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64;  // first row of this wave
-    const size_t row = row0 + lane;
-    const bool active = row < N;
-
-    const int ablate = mode >> 8;  // profiling aid: 1 = skip the store stream, 2 = skip the simulation
-    mode &= 0xFF;
     if (active && !(ablate & 2)) {
-        const int e = (int)(row / A);
-        const uint32_t i = (uint32_t)(row % A);
         EnvState<A, NIW> s;
-        load_state<A, NIW>(s, state, P.E, e, P.NP);
+        unpack_state<A, NIW>(s, raw);
         {
             const uint64_t g = (((uint64_t)P.env_base_hi << 32) | P.env_base_lo) + (uint64_t)e;
-            uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
+            const uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
             s.rng.key = mix32(k ^ (uint32_t)(g >> 32));
         }
         if (mode == 0) {
-            uint32_t act[A];
-            static_for<0, A>([&](auto K) {
-                const size_t r = (size_t)e * A + K.value;
-                act[K.value] = act_size == 8 ? (uint32_t) reinterpret_cast<const long long*>(actions)[r]
-                             : act_size == 4 ? (uint32_t) reinterpret_cast<const int*>(actions)[r]
-                                             : (uint32_t) reinterpret_cast<const uint8_t*>(actions)[r];
-            });
             uint32_t onion_mask, dish_mask, deliver_mask;
-            onion_mask = dish_mask = deliver_mask = 0;
-            if (!(ablate & 4)) step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
+            step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
             // rewards accumulate as Python floats in the config's list order
             // [onion_in_pot 0.1, soup_in_dish 0.3, delivery 1.0 shared] (overcooked_config.py:96)
             double r = 0.0;
-            if ((onion_mask >> i) & 1u) r += 0.1;
-            if ((dish_mask >> i) & 1u) r += 0.3;
-            static_for<0, A>([&](auto K) { if ((deliver_mask >> K.value) & 1u) r += 1.0; });
+            r += ((onion_mask >> i) & 1u) ? 0.1 : 0.0;
+            r += ((dish_mask >> i) & 1u) ? 0.3 : 0.0;
+            static_for<0, A>([&](auto K) { r += ((deliver_mask >> K.value) & 1u) ? 1.0 : 0.0; });
             const bool trunc = s.t >= (uint32_t)P.max_steps;
             rewards[row] = (float)r;
             terminated[row] = 0;
             truncated[row] = trunc ? 1 : 0;
             // vector-env semantics: a finished env restarts at once and reports the first
             // observation of the new episode together with the done flags
-            if (trunc) reset_env<A, NIW>(s, T, P, nullptr, nullptr, e);
-            if (i == 0) store_state<A, NIW>(s, state, P.E, e, P.NP);
+            if (trunc) reset_env<A, NIW>(s, T, P, nullptr, nullptr, aux_g, e);
+            if (i == 0) store_state<A, NIW>(s, state, P.E, e);
         } else if (mode == 1) {
-            reset_env<A, NIW>(s, T, P, spawn_ov, dir_ov, e);
-            if (i == 0) store_state<A, NIW>(s, state, P.E, e, P.NP);
+            reset_env<A, NIW>(s, T, P, spawn_ov, dir_ov, aux_g, e);
+            if (i == 0) store_state<A, NIW>(s, state, P.E, e);
         }
 
         Block<NW> blk;
-        if (!(ablate & 8)) build_block<A, FEAT, NIW>(blk, s, T, P, i);
-        else static_for<0, NW>([&](auto K) { blk.w[K.value] = s.items[0]; });
-        if (ablate & 16) {
-            if (blk.w[0] == 0x12345678u) img[lane] = 1;
-        } else if constexpr (FEAT == FEAT_GLOBAL) {
+        build_block<A, FEAT, NIW>(blk, s, T, P, i);
+        if constexpr (FEAT == FEAT_GLOBAL) {
             // my block goes into every row of my env: first in my own, after the lower ids elsewhere
             const uint32_t env_lane0 = (uint32_t)lane - i;
             static_for<0, A>([&](auto J) {
@@ -655,12 +674,12 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, uint32_t* __restrict_
 // dispatch
 // ---------------------------------------------------------------------------------------
 template <int A, int FEAT, int NIW>
-static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, uint32_t* state, const void* actions,
+static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8_t* aux, uint32_t* state, const void* actions,
                              int act_size, const uint8_t* prio, const uint8_t* spawn_ov, const uint8_t* dir_ov,
                              float* obs, float* rewards, uint8_t* term, uint8_t* trunc, int mode,
                              hipStream_t stream) {
     using G = FeatGeom<A, FEAT>;
-    // 4 waves per workgroup unless their row images would not leave room for two workgroups per CU
+    // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
     int waves = 4;
     while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * 64 * G::D > 64 * 1024) waves >>= 1;
     const size_t lds = (size_t)P.tab_bytes + (size_t)waves * 64 * G::D;
@@ -676,17 +695,17 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, uint32_t* s
     const size_t N = (size_t)P.E * A;
     const size_t rows_per_block = (size_t)waves * 64;
     const unsigned grid = (unsigned)((N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((env_kernel<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, state,
+    hipLaunchKernelGGL((env_kernel<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
                        actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
     return hipGetLastError();
 }
 
 template <int A, int FEAT>
-static hipError_t launch_niw(int niw, const EnvParams& P, const uint8_t* tab, uint32_t* state,
+static hipError_t launch_niw(int niw, const EnvParams& P, const uint8_t* tab, const uint8_t* aux, uint32_t* state,
                              const void* actions, int act_size, const uint8_t* prio, const uint8_t* spawn_ov,
                              const uint8_t* dir_ov, float* obs, float* rewards, uint8_t* term, uint8_t* trunc,
                              int mode, hipStream_t stream) {
-#define OC_GO(NIW_) return launch_one<A, FEAT, NIW_>(P, tab, state, actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode, stream)
+#define OC_GO(NIW_) return launch_one<A, FEAT, NIW_>(P, tab, aux, state, actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode, stream)
     switch (niw) {
         case 1: OC_GO(1);
         case 2: OC_GO(2);
@@ -698,11 +717,12 @@ static hipError_t launch_niw(int niw, const EnvParams& P, const uint8_t* tab, ui
 }
 
 template <int A>
-hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint8_t* tab, uint32_t* state,
+hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint8_t* tab, const uint8_t* aux,
+                               uint32_t* state,
                                const void* actions, int act_size, const uint8_t* prio, const uint8_t* spawn_ov,
                                const uint8_t* dir_ov, float* obs, float* rewards, uint8_t* term, uint8_t* trunc,
                                int mode, hipStream_t stream) {
-#define OC_GO(FEAT_) return launch_niw<A, FEAT_>(niw, P, tab, state, actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode, stream)
+#define OC_GO(FEAT_) return launch_niw<A, FEAT_>(niw, P, tab, aux, state, actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode, stream)
     switch (feat) {
         case FEAT_GLOBAL: OC_GO(FEAT_GLOBAL);
         case FEAT_LOCAL: OC_GO(FEAT_LOCAL);
@@ -717,7 +737,7 @@ hipError_t launch_env_kernel_A(int feat, int niw, const EnvParams& P, const uint
 #ifndef OC_AGENTS
 #error "compile with -DOC_AGENTS=<1|2|4>: one translation unit per agent count"
 #endif
-template hipError_t launch_env_kernel_A<OC_AGENTS>(int, int, const EnvParams&, const uint8_t*, uint32_t*, const void*,
+template hipError_t launch_env_kernel_A<OC_AGENTS>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*,
                                                    int, const uint8_t*, const uint8_t*, const uint8_t*, float*, float*,
                                                    uint8_t*, uint8_t*, int, hipStream_t);
 

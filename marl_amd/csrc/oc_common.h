@@ -1,6 +1,6 @@
 // Shared between host table builder and device kernels: constants, feature-block
-// geometry and the byte layout of the per-layout lookup blob that every workgroup
-// stages into LDS.
+// geometry, the packed per-env state layout and the layout of the lookup blob that every
+// workgroup stages into LDS.
 #pragma once
 
 #include <stdint.h>
@@ -21,7 +21,8 @@ enum : uint32_t { DIR_RIGHT = 0, DIR_DOWN = 1, DIR_LEFT = 2, DIR_UP = 3 };
 constexpr int POT_CAPACITY = 3;
 constexpr int COOK_TIME = 30;
 constexpr int MAX_CELLS = 256;
-constexpr int MAX_POTS = 8;
+constexpr int MAX_POTS = 4;     // one byte per pot in a single state word
+constexpr int MAX_SLOTS = 126;  // item-capable cells; 127 is the "no slot" code
 constexpr int MAX_AGENTS = 4;
 
 // pot condition classes and where each lands in the two pot encodings.
@@ -58,7 +59,8 @@ struct FeatGeom {
     static constexpr int O_POS = O_OTHERS + (kOthers ? 2 * (A - 1) : 0);
     static constexpr int O_CAN_MOVE = O_POS + 2;
     static constexpr int BLK = kSpatial ? O_CAN_MOVE + 4 : 4;
-    static constexpr int NW = (BLK + 3) / 4;  // block padded to dwords
+    static constexpr int NW = (BLK + 3) / 4;      // block padded to dwords
+    static constexpr int NWP = (NW + 3) / 4 * 4;  // template row stride in dwords (16-byte rows)
     static constexpr int D = (FEAT == FEAT_GLOBAL) ? A * BLK : BLK;
 };
 
@@ -73,48 +75,58 @@ inline int block_dim(int A, int feat) {
     return -1;
 }
 
-// ---- lookup blob (bytes) ----
-constexpr int TAB_CELLTYPE = 0;        // u8[256]
-constexpr int TAB_SLOT_OF_CELL = 256;  // u8[256], 0xFF = cell cannot hold an item
-constexpr int TAB_POT_OF_CELL = 512;   // u8[256]
-constexpr int TAB_FIDX_OF_CELL = 768;  // u8[256], index among floor cells
-constexpr int TAB_CELL_RC = 1024;      // u16[256], (row << 8) | col
-constexpr int TAB_CELL_OF_SLOT = 1536; // u8[256]
-constexpr int TAB_FLOOR_CELL = 1792;   // u8[256], floor cells in scan order
-constexpr int TAB_SPAWN_CELL = 2048;   // u8[256], '+' cells in scan order
-constexpr int TAB_POT_ORDER = 2304;    // u8[256][2], two nearest pots per cell (0xFF = none)
-constexpr int TAB_POT_CELL = 2816;     // u8[8]
-constexpr int TAB_POSTAB = 2832;       // i8[nfloor][NW*4] static part of the block per floor cell
+// ---- neighbour word: what lies one step from a floor cell in one direction ----
+//   bits 0-2   cell type
+//   bits 3-9   item slot of that cell (127 = cannot hold an item)
+//   bits 10-12 pot id (7 = not a pot)
+//   bits 16-23 floor index of that cell (valid when the type is FLOOR)
+constexpr uint32_t NB_NO_SLOT = 127;
+constexpr uint32_t NB_NO_POT = 7;
+inline uint32_t nb_pack(uint32_t type, uint32_t slot, uint32_t pot, uint32_t fidx) {
+    return type | (slot << 3) | (pot << 10) | (fidx << 16);
+}
 
+// ---- hot lookup blob, indexed by FLOOR INDEX (agents only ever stand on floor cells) ----
+// All offsets are multiples of 16 bytes and live in EnvParams.
+//   nb       uint32[nfloor][4]     neighbour words in direction order (right, down, left, up)
+//   postab   uint32[nfloor][NWP]   static part of the feature block of an agent standing there
+//   frc      uint16[nfloor]        (row << 8) | col of the floor cell
+//   slotrc   uint16[nslots]        (row << 8) | col of each item slot (slots are in row-major cell order)
+//   potorder uint8[nfloor][2]      the two nearest pots (0xFF = none)
+//   spawnf   uint8[nspawn]         floor indices of the '+' cells
 struct EnvParams {
     int E;            // envs in this shard
-    int W;            // grid width
     int NP;           // pots
     int nslots;       // cells that can hold an item
     int nfloor;
     int nspawn;
     int max_steps;
-    int tab_bytes;    // size of the lookup blob, multiple of 16
+    int tab_bytes;    // size of the hot blob, multiple of 16
     int dist_metric;  // 0 = L1, 1 = squared L2
-    uint32_t seed_key;          // mix of the 64-bit seed
+    int off_nb, off_postab, off_frc, off_slotrc, off_potorder, off_spawnf;
+    uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard
 };
+
+// ---- auxiliary tables for the snapshot kernels (global memory, cell-indexed) ----
+constexpr int AUX_FLOOR_CELL = 0;      // u8[256] floor index -> cell
+constexpr int AUX_FIDX_OF_CELL = 256;  // u8[256] cell -> floor index
+constexpr int AUX_SLOT_OF_CELL = 512;  // u8[256] cell -> item slot (0xFF none)
+constexpr int AUX_CELL_OF_SLOT = 768;  // u8[256] item slot -> cell
+constexpr int AUX_BYTES = 1024;
 
 // per-env packed state, struct-of-arrays: word w of env e lives at state[w * E + e]
 //   word 0: t (bits 0-15)
 //   word 1: RNG draw counter
-//   word 2 [,3]: pots, one byte each: count (bits 0-1) | timer (bits 2-6); word 3 only if NP > 4
-//   then (A+1)/2 agent words, 16 bits per agent: cell (0-7) | dir (8-9) | inv (10-11)
+//   word 2: pots, one byte each: count (bits 0-1) | timer (bits 2-6)
+//   then (A+1)/2 agent words, 16 bits per agent: floor index (0-7) | dir (8-9) | inv (10-11)
 //   then NIW item words, 2 bits per item slot
-inline int pot_words(int NP) { return NP > 4 ? 2 : 1; }
 inline int agent_words(int A) { return (A + 1) / 2; }
 inline int item_words_exact(int nslots) { return (nslots + 15) / 16; }
 inline int item_words_padded(int nslots) {
     int w = item_words_exact(nslots);
     return w <= 1 ? 1 : w <= 2 ? 2 : w <= 4 ? 4 : 8;
 }
-inline int state_words(int A, int NP, int nslots) {
-    return 2 + pot_words(NP) + agent_words(A) + item_words_padded(nslots);
-}
+inline int state_words(int A, int nslots) { return 3 + agent_words(A) + item_words_padded(nslots); }
 
 }  // namespace oc

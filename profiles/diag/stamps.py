@@ -1,0 +1,26 @@
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.getcwd())
+from marl_amd.env import BatchedOvercookedVecEnv
+from marl_amd.layouts import get_layout
+E, A = 65536, 2
+env = BatchedOvercookedVecEnv(get_layout("overcooked_cramped_room_v0"), A, "global_obs", E, seed=1)
+N, D = env.N, env.D
+obs = torch.empty((N, D), device="cuda"); rew = torch.empty(N, device="cuda")
+term = torch.empty(N, dtype=torch.bool, device="cuda"); trunc = torch.empty_like(term)
+env.reset(out=obs)
+nw = N // 64
+dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
+acts = torch.randint(0, 7, (8, N), device="cuda")
+for i in range(50):
+    env.step_into(acts[i % 8], obs, rew, term, trunc, prio_override=dbg)
+torch.cuda.synchronize()
+s = dbg.cpu().numpy().reshape(nw, 8)
+t0 = s[:, 0].min()
+d = np.diff(s, axis=1)
+names = ["loads+stage+barrier", "unpack+key", "step_env", "rewards/store_state", "build_block", "write_block", "barrier+stream"]
+print("per-wave cycles (median / p10 / p90):")
+for k, n in enumerate(names):
+    print(f"  {n:22s} {np.median(d[:,k]):8.0f} {np.percentile(d[:,k],10):8.0f} {np.percentile(d[:,k],90):8.0f}")
+print("start spread (cycles):", np.percentile(s[:,0]-t0, [50, 90, 100]))
+print("end - first start (cycles): median", np.median(s[:,7]-t0), "max", (s[:,7]-t0).max())
+print("total per wave median", np.median(s[:,7]-s[:,0]))
