@@ -26,6 +26,14 @@
 
 #include "oc_common.h"
 
+// Cache policy of the observation stores (buffer-instruction aux bits on gfx950: 1 = sc0,
+// 2 = nt, 16 = sc1).  sc1 = write-through: the 106 MB a launch writes do not stay dirty in the
+// XCD L2s, so the end-of-kernel write-back has nothing left to flush.  Measured on the headline
+// config: plain 21.5 us, nt 25.3 us, sc1 20.1 us per launch.
+#ifndef OC_STORE_AUX
+#define OC_STORE_AUX 16
+#endif
+
 namespace oc {
 
 // ---------------------------------------------------------------------------------------
@@ -646,26 +654,32 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     }
     __syncthreads();
 
-    // stream the wave's rows out: 4 int8 -> 4 floats -> one 16-byte store per lane
+    // stream the wave's rows out: 4 int8 -> 4 floats -> one 16-byte store per lane.  The stores
+    // go through a wave-uniform buffer descriptor over exactly this wave's rows (the hardware
+    // range check drops anything past the end).
     if (row0 < N && !(ablate & 1)) {
         const size_t rows_here = (N - row0) < 64 ? (N - row0) : 64;
-        const uint32_t nchunk = (uint32_t)(rows_here * D) / 4;  // 64*D is a multiple of 4; tails handled below
+        const uint32_t nfloat = (uint32_t)(rows_here * D);
+        const uint32_t nchunk = nfloat / 4;  // 64*D is a multiple of 4; the tail of a short last group is handled below
         const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
-        float4* out = reinterpret_cast<float4*>(obs + row0 * D);
+        float* out = obs + row0 * D;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, nchunk * 16u, 0x00020000);
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
         for (uint32_t q = lane; q < nchunk; q += 64) {
             const uint32_t v = img32[q];
-            float4 f;
+            f32x4 f;
             f.x = (float)(int)(int8_t)(v);
             f.y = (float)(int)(int8_t)(v >> 8);
             f.z = (float)(int)(int8_t)(v >> 16);
             f.w = (float)(int)(int8_t)(v >> 24);
-            out[q] = f;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, q * 16u, 0, OC_STORE_AUX);
         }
         // a short last group can leave up to 3 floats past the last full chunk
-        const uint32_t rem = (uint32_t)(rows_here * D) & 3u;
+        const uint32_t rem = nfloat & 3u;
         if (rem && lane < (int)rem) {
             const uint32_t idx = nchunk * 4 + lane;
-            obs[row0 * D + idx] = (float)(int)(int8_t)img[idx];
+            out[idx] = (float)(int)(int8_t)img[idx];
         }
     }
 }

@@ -9,12 +9,13 @@ obs = torch.empty((N, D), device="cuda"); rew = torch.empty(N, device="cuda")
 term = torch.empty(N, dtype=torch.bool, device="cuda"); trunc = torch.empty_like(term)
 env.reset(out=obs)
 nw = N // 64
-dbg = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nw * 10, dtype=torch.int64, device="cuda")
 acts = torch.randint(0, 7, (8, N), device="cuda")
 for i in range(50):
     env.step_into(acts[i % 8], obs, rew, term, trunc, prio_override=dbg)
 torch.cuda.synchronize()
-s = dbg.cpu().numpy().reshape(nw, 8)
+full = dbg.cpu().numpy().reshape(nw, 10)
+s = full[:, :8]
 t0 = s[:, 0].min()
 d = np.diff(s, axis=1)
 names = ["loads+stage+barrier", "unpack+key", "step_env", "rewards/store_state", "build_block", "write_block", "barrier+stream"]
@@ -24,3 +25,11 @@ for k, n in enumerate(names):
 print("start spread (cycles):", np.percentile(s[:,0]-t0, [50, 90, 100]))
 print("end - first start (cycles): median", np.median(s[:,7]-t0), "max", (s[:,7]-t0).max())
 print("total per wave median", np.median(s[:,7]-s[:,0]))
+
+rt = full[:, 8]
+print("end realtime spread (100MHz ticks): min", rt.min()-rt.min(), "median", np.median(rt)-rt.min(), "max", rt.max()-rt.min())
+for x in range(8):
+    m = full[:, 9] == x
+    if m.any():
+        ss = s[m]
+        print("xcc", x, "waves", m.sum(), "start spread", ss[:,0].max()-ss[:,0].min(), "end spread", ss[:,7].max()-ss[:,0].min(), "median life", np.median(ss[:,7]-ss[:,0]))
