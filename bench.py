@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--layout", default="overcooked_cramped_room_v0")
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--feature", default="global_obs")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python")
+    ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
+    ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,7 +111,7 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
-    if not args.no_graph and args.steps >= R:
+    if args.graph and not args.no_graph and args.steps >= R:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for i in range(R):

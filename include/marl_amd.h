@@ -108,21 +108,24 @@ int marl_env_import_state(marl_env_t *env, void *d_state, const int32_t *d_agent
 
 /*
  * compute_gae + value targets.
- * mode 0: agents/MAPPO.py:82-114 and :144.  d_next_values float32 [N].
+ * mode 0: agents/MAPPO.py:82-114 and :144.  d_next_values float32 [N].  d_workspace unused.
  * mode 1: agents/CentralizedMAPPO.py:48-82: the reward of step t is the mean over all N
- *         rows; d_next_values float32 [1].  d_reward_mean float32 [T] is workspace: when
- *         reward_mean_ready == 0 the call fills it from d_rewards first; a multi-GPU caller
- *         all-reduces its own means and passes reward_mean_ready == 1.
+ *         rows; d_next_values float32 [1].  d_workspace: marl_gae_workspace_bytes(T, N) bytes,
+ *         8-byte aligned; its first T floats are the per-step reward means.  With
+ *         reward_mean_ready == 0 the call computes them from d_rewards; a multi-GPU caller
+ *         all-reduces its own sums, writes the means there and passes reward_mean_ready == 1.
  * d_rewards, d_dones, d_values, d_adv, d_ret: float32 [T][N] (row t contiguous).
  * d_ret may be NULL.  Arithmetic is float32 with every product and sum rounded
  * separately, in the reference's evaluation order.
  */
 int marl_gae(const float *d_rewards, const float *d_dones, const float *d_values,
              const float *d_next_values, int T, int N, double gamma, double lam, float *d_adv,
-             float *d_ret, int mode, float *d_reward_mean, int reward_mean_ready, void *stream);
+             float *d_ret, int mode, void *d_workspace, int reward_mean_ready, void *stream);
+size_t marl_gae_workspace_bytes(int T, int N);
 
-/* per-step reward sums over rows, double [T]; lets a sharded caller form the global mean */
-int marl_row_sums(const float *d_x, int T, int N, double *d_sums, void *stream);
+/* per-step sums over rows, double [T] (fixed summation order); lets a sharded caller form the
+ * global reward mean.  d_workspace as for marl_gae. */
+int marl_row_sums(const float *d_x, int T, int N, double *d_sums, void *d_workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ EXPORTS = (
     "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_obs_dim", "marl_env_num_rows",
     "marl_env_num_pots", "marl_env_grid_cells", "marl_env_state_words", "marl_env_state_bytes",
     "marl_env_reset", "marl_env_step", "marl_env_featurize", "marl_env_export_state",
-    "marl_env_import_state", "marl_gae", "marl_row_sums",
+    "marl_env_import_state", "marl_gae", "marl_gae_workspace_bytes", "marl_row_sums",
 )
 
 _lib = None
@@ -61,8 +61,10 @@ def lib() -> ctypes.CDLL:
     L.marl_env_import_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.marl_gae.restype = ci
     L.marl_gae.argtypes = [vp, vp, vp, vp, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp, ci, vp, ci, vp]
+    L.marl_gae_workspace_bytes.restype = ctypes.c_size_t
+    L.marl_gae_workspace_bytes.argtypes = [ci, ci]
     L.marl_row_sums.restype = ci
-    L.marl_row_sums.argtypes = [vp, ci, ci, vp, vp]
+    L.marl_row_sums.argtypes = [vp, ci, ci, vp, vp, vp]
     _lib = L
     return L
 

@@ -32,7 +32,9 @@ extern template hipError_t launch_env_kernel_A<4>(int, int, const EnvParams&, co
 hipError_t launch_gae(const float* rewards, const float* dones, const float* values, const float* next_values,
                       int T, int N, float gamma, float gl, float* adv, float* ret, int mode, const float* rmean,
                       hipStream_t stream);
-hipError_t launch_row_sums(const float* x, int T, int N, double* sums, float* mean_out, hipStream_t stream);
+hipError_t launch_row_sums(const float* x, int T, int N, double* partial, double* sums, float* mean_out,
+                           hipStream_t stream);
+int row_sum_chunks(int N);
 }  // namespace oc
 
 using namespace oc;
@@ -401,29 +403,43 @@ extern "C" int marl_env_import_state(marl_env_t* env, void* d_state, const int32
     return e == hipSuccess ? MARL_OK : fail_hip(e, "import kernel launch");
 }
 
-extern "C" int marl_row_sums(const float* d_x, int T, int N, double* d_sums, void* stream) {
-    if (!d_x || !d_sums || T <= 0 || N <= 0) return fail(MARL_ERR_INVALID, "bad argument to marl_row_sums");
-    hipError_t e = launch_row_sums(d_x, T, N, d_sums, nullptr, reinterpret_cast<hipStream_t>(stream));
-    return e == hipSuccess ? MARL_OK : fail_hip(e, "row_sum kernel launch");
+// workspace: [T floats: per-step reward mean, padded to 8 bytes][T * chunks doubles: partial sums]
+static size_t ws_mean_bytes(int T) { return ((size_t)T * sizeof(float) + 7) & ~(size_t)7; }
+
+extern "C" size_t marl_gae_workspace_bytes(int T, int N) {
+    if (T <= 0 || N <= 0) return 0;
+    return ws_mean_bytes(T) + (size_t)T * (size_t)row_sum_chunks(N) * sizeof(double);
+}
+
+extern "C" int marl_row_sums(const float* d_x, int T, int N, double* d_sums, void* d_workspace, void* stream) {
+    if (!d_x || !d_sums || !d_workspace || T <= 0 || N <= 0) return fail(MARL_ERR_INVALID, "bad argument to marl_row_sums");
+    if (((uintptr_t)d_workspace & 7u) != 0) return fail(MARL_ERR_INVALID, "d_workspace must be 8-byte aligned");
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(d_workspace) + ws_mean_bytes(T));
+    hipError_t e = launch_row_sums(d_x, T, N, partial, d_sums, nullptr, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "row sum kernel launch");
 }
 
 extern "C" int marl_gae(const float* d_rewards, const float* d_dones, const float* d_values,
                         const float* d_next_values, int T, int N, double gamma, double lam, float* d_adv, float* d_ret,
-                        int mode, float* d_reward_mean, int reward_mean_ready, void* stream) {
+                        int mode, void* d_workspace, int reward_mean_ready, void* stream) {
     if (!d_rewards || !d_dones || !d_values || !d_next_values || !d_adv)
         return fail(MARL_ERR_INVALID, "NULL argument to marl_gae");
     if (T <= 0 || N <= 0) return fail(MARL_ERR_INVALID, "T and N must be positive");
     if (mode != 0 && mode != 1) return fail(MARL_ERR_INVALID, "mode must be 0 (MAPPO) or 1 (CMAPPO)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* mean = nullptr;
     if (mode == 1) {
-        if (!d_reward_mean) return fail(MARL_ERR_INVALID, "mode 1 needs the d_reward_mean workspace (float32[T])");
+        if (!d_workspace) return fail(MARL_ERR_INVALID, "mode 1 needs d_workspace (marl_gae_workspace_bytes(T, N) bytes)");
+        if (((uintptr_t)d_workspace & 7u) != 0) return fail(MARL_ERR_INVALID, "d_workspace must be 8-byte aligned");
+        mean = reinterpret_cast<float*>(d_workspace);
         if (!reward_mean_ready) {
-            hipError_t e = launch_row_sums(d_rewards, T, N, nullptr, d_reward_mean, s);
-            if (e != hipSuccess) return fail_hip(e, "row_sum kernel launch");
+            double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(d_workspace) + ws_mean_bytes(T));
+            hipError_t e = launch_row_sums(d_rewards, T, N, partial, nullptr, mean, s);
+            if (e != hipSuccess) return fail_hip(e, "row sum kernel launch");
         }
     }
     // Python forms gamma * lam in double; each scalar is rounded to float32 when it meets a tensor
     hipError_t e = launch_gae(d_rewards, d_dones, d_values, d_next_values, T, N, (float)gamma, (float)(gamma * lam),
-                              d_adv, d_ret, mode, d_reward_mean, s);
+                              d_adv, d_ret, mode, mean, s);
     return e == hipSuccess ? MARL_OK : fail_hip(e, "gae kernel launch");
 }

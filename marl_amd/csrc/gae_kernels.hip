@@ -74,24 +74,37 @@ gae_kernel(const float* __restrict__ rewards, const float* __restrict__ dones, c
     }
 }
 
-// one workgroup per row t: sum of x[t][0..N) in double, fixed order => reproducible
+// Row sums in two fixed-order passes (reproducible run to run): pass 1, workgroup (c, t) adds
+// chunk c of row t in double; pass 2, one lane per row adds that row's chunk sums in order.
 __global__ void __launch_bounds__(256)
-row_sum_kernel(const float* __restrict__ x, int N, double* __restrict__ sums, float* __restrict__ mean_out) {
-    const int t = blockIdx.x;
+row_partial_kernel(const float* __restrict__ x, int N, int chunk, int C, double* __restrict__ partial) {
+    const int c = blockIdx.x, t = blockIdx.y;
     const float* row = x + (size_t)t * N;
+    const int lo = c * chunk;
+    const int hi = min(N, lo + chunk);
     double acc = 0.0;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) acc += (double)row[n];
+    for (int n = lo + (int)threadIdx.x; n < hi; n += (int)blockDim.x) acc += (double)row[n];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
-        if (sums) sums[t] = s;
-        if (mean_out) mean_out[t] = (float)(s / (double)N);
-    }
+    if (threadIdx.x == 0) partial[(size_t)t * C + c] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void row_finish_kernel(const double* __restrict__ partial, int T, int C, int N, double* __restrict__ sums,
+                                  float* __restrict__ mean_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += partial[(size_t)t * C + c];
+    if (sums) sums[t] = s;
+    if (mean_out) mean_out[t] = (float)(s / (double)N);
+}
+
+int row_sum_chunks(int N) {
+    int c = (N + 8191) / 8192;
+    return c < 1 ? 1 : c > 64 ? 64 : c;
 }
 
 hipError_t launch_gae(const float* rewards, const float* dones, const float* values, const float* next_values,
@@ -104,8 +117,14 @@ hipError_t launch_gae(const float* rewards, const float* dones, const float* val
     return hipGetLastError();
 }
 
-hipError_t launch_row_sums(const float* x, int T, int N, double* sums, float* mean_out, hipStream_t stream) {
-    hipLaunchKernelGGL(row_sum_kernel, dim3(T), dim3(256), 0, stream, x, N, sums, mean_out);
+hipError_t launch_row_sums(const float* x, int T, int N, double* partial, double* sums, float* mean_out,
+                           hipStream_t stream) {
+    const int C = row_sum_chunks(N);
+    const int chunk = (N + C - 1) / C;
+    hipLaunchKernelGGL(row_partial_kernel, dim3(C, T), dim3(256), 0, stream, x, N, chunk, C, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(row_finish_kernel, dim3((T + 63) / 64), dim3(64), 0, stream, partial, T, C, N, sums, mean_out);
     return hipGetLastError();
 }
 

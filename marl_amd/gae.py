@@ -17,6 +17,11 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _workspace(T, N, device):
+    nbytes = int(_lib.lib().marl_gae_workspace_bytes(int(T), int(N)))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 def _f32c(t, name):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise ValueError(f"{name} must be a float32 tensor on the GPU")
@@ -38,19 +43,20 @@ def compute_gae(rewards, dones, values, next_values, gamma=0.99, lam=0.95, centr
     adv = torch.empty_like(rewards)
     ret = torch.empty_like(rewards) if want_returns else None
     ready = 0
+    workspace = None
     if centralised:
-        if reward_mean is None:
-            reward_mean = torch.empty(T, dtype=torch.float32, device=rewards.device)
-        else:
+        workspace = _workspace(T, N, rewards.device)
+        if reward_mean is not None:
             reward_mean = _f32c(reward_mean, "reward_mean")
             if reward_mean.numel() != T:
                 raise ValueError("reward_mean must have T entries")
+            workspace[: T * 4].view(torch.float32).copy_(reward_mean.reshape(-1))
             ready = 1
     stream = ctypes.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
     with torch.cuda.device(rewards.device):
         _lib.check(_lib.lib().marl_gae(_ptr(rewards), _ptr(dones), _ptr(values), _ptr(next_values), T, N,
                                        float(gamma), float(lam), _ptr(adv), _ptr(ret), 1 if centralised else 0,
-                                       _ptr(reward_mean), ready, stream), "marl_gae")
+                                       _ptr(workspace), ready, stream), "marl_gae")
     return adv, ret
 
 
@@ -59,7 +65,8 @@ def row_sums(x):
     x = _f32c(x, "x")
     T, N = x.shape
     out = torch.empty(T, dtype=torch.float64, device=x.device)
+    workspace = _workspace(T, N, x.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().marl_row_sums(_ptr(x), T, N, _ptr(out), stream), "marl_row_sums")
+        _lib.check(_lib.lib().marl_row_sums(_ptr(x), T, N, _ptr(out), _ptr(workspace), stream), "marl_row_sums")
     return out

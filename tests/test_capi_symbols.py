@@ -41,5 +41,6 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     rc = L.marl_env_create(ctypes.byref(handle), open_grid, 3, 1, 0, 1000, 4, 0, 0, 0)
     assert rc == -2 and b"enclosed" in L.marl_last_error()
     rc = L.marl_gae(None, None, None, None, 4, 4, 0.99, 0.95, None, None, 0, None, 0, None)
+    assert L.marl_gae_workspace_bytes(128, 131072) == 128 * 4 + 128 * 16 * 8
     assert rc == -1
     assert L.marl_env_obs_dim(None) == -1
