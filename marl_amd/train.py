@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import os
 import random
+import sys
 import time
 
 import numpy as np
@@ -105,7 +106,7 @@ def main(argv=None):
 
     t0 = time.time()
     returns, freq = agent_environment_loop(agent, vec_env, device, num_update=num_updates, log_dir=log_dir, args=args,
-                                           writer=writer, progress=(rank == 0))
+                                           writer=writer, progress=(rank == 0 and sys.stderr.isatty()))
     torch.cuda.synchronize()
     dt = time.time() - t0
     if rank == 0:
