@@ -60,6 +60,14 @@ int marl_env_create(marl_env_t **out, const char *const *layout_rows, int height
                     int dist_metric);
 void marl_env_destroy(marl_env_t *env);
 
+/*
+ * The reference steps cogrid through a vector wrapper that restarts a finished env inside
+ * step() (default here, enabled = 1).  A bare cogrid env (tests/test_load.py:104-111) does not:
+ * with enabled = 0 a truncated env keeps its final state and observation, t keeps counting,
+ * and the caller resets.
+ */
+int marl_env_set_auto_reset(marl_env_t *env, int enabled);
+
 /* shape queries */
 int marl_env_obs_dim(const marl_env_t *env);       /* D: single_observation_space.shape[0], main.py:92 */
 int marl_env_num_rows(const marl_env_t *env);      /* E * A: vec_env.num_envs, main.py:186 */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "libmarl_amd.so")  # override: diagnostic builds
 
 EXPORTS = (
-    "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_obs_dim", "marl_env_num_rows",
+    "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_set_auto_reset", "marl_env_obs_dim", "marl_env_num_rows",
     "marl_env_num_pots", "marl_env_grid_cells", "marl_env_state_words", "marl_env_state_bytes",
     "marl_env_reset", "marl_env_step", "marl_env_featurize", "marl_env_export_state",
     "marl_env_import_state", "marl_gae", "marl_gae_workspace_bytes", "marl_row_sums",
@@ -47,6 +47,8 @@ def lib() -> ctypes.CDLL:
                  "marl_env_state_words"):
         getattr(L, name).restype = ci
         getattr(L, name).argtypes = [vp]
+    L.marl_env_set_auto_reset.restype = ci
+    L.marl_env_set_auto_reset.argtypes = [vp, ci]
     L.marl_env_state_bytes.restype = ctypes.c_size_t
     L.marl_env_state_bytes.argtypes = [vp]
     L.marl_env_reset.restype = ci

@@ -296,7 +296,7 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     int rc = build_tables(env, layout_rows, height, dist_metric);
     if (rc != MARL_OK) { delete env; return rc; }
     EnvParams& P = env->P;
-    P.E = num_envs; P.max_steps = max_steps;
+    P.E = num_envs; P.max_steps = max_steps; P.auto_reset = 1;
     uint32_t k = mix32_host((uint32_t)seed + 0x9E3779B9u);
     P.seed_key = mix32_host(k ^ (uint32_t)(seed >> 32));
     P.env_base_lo = (uint32_t)(uint64_t)env_index_base;
@@ -320,6 +320,12 @@ extern "C" void marl_env_destroy(marl_env_t* env) {
     if (env->d_tab) (void)hipFree(env->d_tab);
     if (env->d_aux) (void)hipFree(env->d_aux);
     delete env;
+}
+
+extern "C" int marl_env_set_auto_reset(marl_env_t* env, int enabled) {
+    if (!env) return fail(MARL_ERR_INVALID, "env is NULL");
+    env->P.auto_reset = enabled ? 1 : 0;
+    return MARL_OK;
 }
 
 extern "C" int marl_env_obs_dim(const marl_env_t* env) { return env ? env->D : MARL_ERR_INVALID; }

@@ -631,7 +631,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             truncated[row] = trunc ? 1 : 0;
             // vector-env semantics: a finished env restarts at once and reports the first
             // observation of the new episode together with the done flags
-            if (trunc) reset_env<A, NIW>(s, T, P, nullptr, nullptr, aux_g, e);
+            if (trunc && P.auto_reset) reset_env<A, NIW>(s, T, P, nullptr, nullptr, aux_g, e);
             if (i == 0) store_state<A, NIW>(s, state, P.E, e);
         } else if (mode == 1) {
             reset_env<A, NIW>(s, T, P, spawn_ov, dir_ov, aux_g, e);

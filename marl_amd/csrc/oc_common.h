@@ -103,6 +103,7 @@ struct EnvParams {
     int max_steps;
     int tab_bytes;    // size of the hot blob, multiple of 16
     int dist_metric;  // 0 = L1, 1 = squared L2
+    int auto_reset;   // 1: a truncated env restarts inside the step (vector-env semantics)
     int off_nb, off_postab, off_frc, off_slotrc, off_potorder, off_spawnf;
     uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard

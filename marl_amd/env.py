@@ -79,6 +79,31 @@ class OvercookedEnvSpec:
             i: Dict({OBS_KEY: Box(-np.inf, np.inf, (d,), np.float32)}) for i in self.agent_ids
         }
         self.action_spaces = {i: Discrete(NUM_ACTIONS) for i in self.agent_ids}
+        self._single = None
+        self._seed = 0
+
+    # -- single-env stepping with per-agent dicts, the shape tests/test_load.py:74-79,104-128 uses --
+    def _env1(self):
+        if self._single is None:
+            self._single = BatchedOvercookedVecEnv(self.layout_rows, self.config["num_agents"],
+                                                   self.config["features"], 1, max_steps=self.config["max_steps"],
+                                                   seed=self._seed, numpy_io=True, auto_reset=False)
+        return self._single
+
+    def reset(self, seed=None, options=None):
+        if seed is not None and (self._single is None or seed != self._seed):
+            self._seed, self._single = int(seed), None
+        obs, _ = self._env1().reset()
+        return {i: {OBS_KEY: obs[OBS_KEY][i]} for i in self.agent_ids}, {i: {} for i in self.agent_ids}
+
+    def step(self, actions):
+        """actions: {agent_id: int}.  Returns per-agent dicts (obs, rewards, terminated, truncated, infos);
+        no restart happens inside the call (a bare env, unlike the vector wrapper)."""
+        act = np.array([int(actions[i]) for i in self.agent_ids], np.int64)
+        obs, rew, term, trunc, _ = self._env1().step(act)
+        ids = self.agent_ids
+        return ({i: {OBS_KEY: obs[OBS_KEY][i]} for i in ids}, {i: float(rew[i]) for i in ids},
+                {i: bool(term[i]) for i in ids}, {i: bool(trunc[i]) for i in ids}, {i: {} for i in ids})
 
 
 def make_env(num_agents=4, layout="large_overcooked_layout", feature="global_obs", render_mode=None, max_steps=1000):
@@ -113,7 +138,7 @@ class BatchedOvercookedVecEnv:
     """
 
     def __init__(self, layout_rows, num_agents, feature="global_obs", num_envs=1, max_steps=1000, seed=0,
-                 env_index_base=0, device=None, numpy_io=False, dist_metric=0):
+                 env_index_base=0, device=None, numpy_io=False, dist_metric=0, auto_reset=True):
         if isinstance(layout_rows, str):
             layout_rows = get_layout(layout_rows)
         if feature not in FEATURE_IDS:
@@ -135,6 +160,9 @@ class BatchedOvercookedVecEnv:
                                                FEATURE_IDS[feature], int(max_steps), self.E, int(seed),
                                                int(env_index_base), int(dist_metric)), "marl_env_create")
         self._h = handle
+        if not auto_reset:
+            _lib.check(self._L.marl_env_set_auto_reset(self._h, 0), "marl_env_set_auto_reset")
+        self.auto_reset = bool(auto_reset)
         self.D = self._L.marl_env_obs_dim(self._h)
         self.NP = self._L.marl_env_num_pots(self._h)
         self.state_words = self._L.marl_env_state_words(self._h)

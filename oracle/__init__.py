@@ -43,6 +43,7 @@ class _Layout(ctypes.Structure):
     _fields_ = [
         ("H", ctypes.c_int), ("W", ctypes.c_int), ("A", ctypes.c_int),
         ("max_steps", ctypes.c_int), ("feature", ctypes.c_int), ("dist_metric", ctypes.c_int),
+        ("auto_reset", ctypes.c_int),
         ("type", ctypes.c_ubyte * 256),
         ("nspawn", ctypes.c_int), ("spawn", ctypes.c_int * 256),
         ("npots", ctypes.c_int), ("pot_cell", ctypes.c_int * 8),
@@ -88,7 +89,7 @@ class OracleVecEnv:
     """E independent Overcooked envs stepped on the CPU, canonical-snapshot state in numpy."""
 
     def __init__(self, layout_rows, num_agents, feature="global_obs", max_steps=1000, num_envs=1,
-                 seed=0, env_index_base=0, dist_metric=0, nthreads=1):
+                 seed=0, env_index_base=0, dist_metric=0, nthreads=1, auto_reset=True):
         self._lib = lib()
         self.layout = _Layout()
         rows = (ctypes.c_char_p * len(layout_rows))(*[r.encode() for r in layout_rows])
@@ -97,6 +98,7 @@ class OracleVecEnv:
                                       max_steps, dist_metric)
         if rc != 0:
             raise ValueError(f"oc_layout_init failed with {rc}")
+        self.layout.auto_reset = 1 if auto_reset else 0
         self.E, self.A = int(num_envs), int(num_agents)
         self.H, self.W = self.layout.H, self.layout.W
         self.NP = self.layout.npots

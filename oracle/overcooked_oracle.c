@@ -61,7 +61,7 @@ int oc_layout_init(oc_layout *L, const char *const *rows, int H, int num_agents,
     int W = (int)strlen(rows[0]);
     if (W <= 0 || H * W > OC_MAX_CELLS) return -2;
     L->H = H; L->W = W; L->A = num_agents;
-    L->max_steps = max_steps; L->feature = feature; L->dist_metric = dist_metric;
+    L->max_steps = max_steps; L->feature = feature; L->dist_metric = dist_metric; L->auto_reset = 1;
     for (int r = 0; r < H; ++r) {
         if ((int)strlen(rows[r]) != W) return -3;
         for (int c = 0; c < W; ++c) {
@@ -576,7 +576,7 @@ void oc_step_batch(const oc_layout *L, int E, uint64_t seed, int64_t env_index_b
         int all_done = 1;
         for (int a = 0; a < A; ++a)
             if (!(terminated[(size_t)e * A + a] || truncated[(size_t)e * A + a])) all_done = 0;
-        if (all_done) env_reset(L, &s, seed, env_index_base + e, NULL, NULL);
+        if (all_done && L->auto_reset) env_reset(L, &s, seed, env_index_base + e, NULL, NULL);
         env_store(L, &s, agents + (size_t)e * A * 4, pots + (size_t)e * NP * 2, items + (size_t)e * NC, misc + (size_t)e * 2);
         if (obs)
             for (int a = 0; a < A; ++a) featurize_agent(L, &s, a, obs + ((size_t)e * A + a) * D);

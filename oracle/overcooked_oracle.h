@@ -58,6 +58,7 @@ typedef struct oc_layout {
     int max_steps;
     int feature;      /* OC_FEAT_* */
     int dist_metric;  /* 0 = L1 (|dy|+|dx|), 1 = squared L2 */
+    int auto_reset;   /* 1 (default): the vector wrapper restarts a finished env inside step */
     unsigned char type[OC_MAX_CELLS];
     int nspawn;
     int spawn[OC_MAX_CELLS]; /* '+' cells in scan order */

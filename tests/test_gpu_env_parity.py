@@ -135,3 +135,28 @@ def test_full_size_properties():
     # observations are small integers: nothing outside what int8 staging can hold
     assert ow[OBS_KEY].abs().max().item() <= 30
     assert torch.equal(ow[OBS_KEY], ow[OBS_KEY].round())
+
+
+def test_single_env_dict_api_without_auto_reset(oracle_mod):
+    """make_env(...) itself steps like a bare cogrid env (tests/test_load.py:74-79,104-128):
+    per-agent dicts, and no restart inside step()."""
+    from marl_amd.env import OBS_KEY, make_env
+
+    env = make_env(num_agents=2, layout="overcooked_forced_coordination_v0", feature="Minimal_spatial_other_agent_aware",
+                   max_steps=12)
+    ora = oracle_mod.OracleVecEnv(get_layout("overcooked_forced_coordination_v0"), 2, "Minimal_spatial_other_agent_aware",
+                                  max_steps=12, num_envs=1, seed=0, auto_reset=False)
+    obs, info = env.reset()
+    oo = ora.reset()
+    assert set(obs) == {0, 1} and obs[0][OBS_KEY].shape == env.observation_spaces[0][OBS_KEY].shape
+    np.testing.assert_array_equal(np.stack([obs[i][OBS_KEY] for i in range(2)]), oo)
+    rng = np.random.default_rng(1)
+    for t in range(15):
+        act = rng.integers(0, 7, size=2)
+        obs, rew, term, trunc, info = env.step({0: int(act[0]), 1: int(act[1])})
+        oo, ro, teo, tro = ora.step(act)
+        np.testing.assert_array_equal(np.stack([obs[i][OBS_KEY] for i in range(2)]), oo)
+        assert [rew[0], rew[1]] == ro.tolist()
+        done = [term[i] or trunc[i] for i in range(2)]
+        assert all(done) == (t + 1 >= 12)       # stays done: nothing restarted the episode
+    assert ora.misc[0, 0] == 15
