@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["random", "policy"], default="random",
+                    help="random: pre-generated uniform actions (headline); policy: actions sampled from the "
+                         "reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm) every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,12 +82,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    backend = os.environ.get("MARL_AMD_DIST_BACKEND", "nccl")  # gloo: several ranks on one GPU (rehearsal only)
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from marl_amd.env import BatchedOvercookedVecEnv
     from marl_amd.layouts import get_layout
@@ -103,8 +112,21 @@ def main():
     trunc = torch.empty(N, dtype=torch.bool, device=dev)
     env.reset(out=obs[0])
 
+    policy = None
+    if args.mode == "policy":
+        from marl_amd.policy import Agent
+
+        torch.manual_seed(1)
+        policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1).to(dev)
+        policy.centralised_critics = None  # not evaluated on the decentralised path
+
     def eager(i):
-        env.step_into(actions[i % R], obs[i % 2], rew, term, trunc)
+        if policy is None:
+            env.step_into(actions[i % R], obs[i % 2], rew, term, trunc)
+        else:
+            with torch.no_grad():
+                act, _, _, _ = policy.get_action_and_value(obs[(i + 1) % 2])
+            env.step_into(act, obs[i % 2], rew, term, trunc)
 
     for i in range(args.warmup):
         eager(i)
@@ -142,7 +164,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
 
     if world > 1:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = tt.tolist()
 
@@ -157,7 +179,8 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get(key)
         out = {
-            "metric": "env agent-steps/sec (fused step+featurize, random actions)",
+            "metric": "env agent-steps/sec (fused step+featurize, random actions)" if policy is None
+                      else "env agent-steps/sec (policy-driven rollout: MLP forward + sample + fused step+featurize)",
             "value": world * N * args.steps / wall,
             "unit": "agent-steps/s",
             "n_gpus": world,
@@ -170,13 +193,17 @@ def main():
             "dtype": "u8/i32 state, f32 observations",
             "data": "synthetic",
             "config": {"workload": f"{args.layout}, {A} agents, {E} envs per GPU, {args.feature} (D={D}), "
-                                   f"uniform random int64 actions, auto-reset at t=1000",
+                                   + ("uniform random int64 actions" if policy is None else "actions sampled from the fp32 MLP policy")
+                                   + ", auto-reset at t=1000",
                        "launch": "hipGraph of 32 steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_agent_step": B, "kernel": "env_kernel<2,global,1> (step+featurize)",
                          "us_per_launch": launch_s * 1e6},
         }
+        if policy is not None:
+            # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
+            out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234, threads)

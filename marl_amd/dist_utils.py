@@ -19,7 +19,8 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MARL_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (tests); RCCL needs one GPU per rank
+            backend = os.environ.get("MARL_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)

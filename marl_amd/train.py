@@ -74,6 +74,7 @@ def main(argv=None):
     if args.render:
         raise SystemExit("--render is not available: there is no renderer in this build")
     rank, local_rank, world = dist_utils.init_from_env()
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
