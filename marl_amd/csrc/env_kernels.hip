@@ -21,6 +21,7 @@
 // others in agent-id order).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -694,7 +695,8 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
                              hipStream_t stream) {
     using G = FeatGeom<A, FEAT>;
     // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
-    int waves = 4;
+    static const int waves_req = [] { const char* v = getenv("MARL_AMD_WAVES"); return v ? atoi(v) : 4; }();  // tuning aid
+    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4) ? waves_req : 4;
     while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * 64 * G::D > 64 * 1024) waves >>= 1;
     const size_t lds = (size_t)P.tab_bytes + (size_t)waves * 64 * G::D;
     static size_t configured[64] = {0};  // per instantiation and device

@@ -153,16 +153,10 @@ class BatchedOvercookedVecEnv:
         self.numpy_io = bool(numpy_io)
         self.layout_rows = list(layout_rows)
         self.H, self.W = len(layout_rows), len(layout_rows[0])
-        rows = (ctypes.c_char_p * len(layout_rows))(*[r.encode() for r in layout_rows])
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(self._L.marl_env_create(ctypes.byref(handle), rows, len(layout_rows), self.A,
-                                               FEATURE_IDS[feature], int(max_steps), self.E, int(seed),
-                                               int(env_index_base), int(dist_metric)), "marl_env_create")
-        self._h = handle
-        if not auto_reset:
-            _lib.check(self._L.marl_env_set_auto_reset(self._h, 0), "marl_env_set_auto_reset")
+        self.seed, self.env_index_base, self.dist_metric = int(seed), int(env_index_base), int(dist_metric)
         self.auto_reset = bool(auto_reset)
+        self._h = None
+        self._create()
         self.D = self._L.marl_env_obs_dim(self._h)
         self.NP = self._L.marl_env_num_pots(self._h)
         self.state_words = self._L.marl_env_state_words(self._h)
@@ -176,6 +170,19 @@ class BatchedOvercookedVecEnv:
         self.action_space = self.single_action_space
         self.state = torch.zeros((self.state_words, self.E), dtype=torch.int32, device=self.device)
         self._closed = False
+
+    def _create(self):
+        rows = (ctypes.c_char_p * len(self.layout_rows))(*[r.encode() for r in self.layout_rows])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.marl_env_create(ctypes.byref(handle), rows, len(self.layout_rows), self.A,
+                                               FEATURE_IDS[self.feature], self.max_steps, self.E, self.seed,
+                                               self.env_index_base, self.dist_metric), "marl_env_create")
+        if self._h:
+            self._L.marl_env_destroy(self._h)
+        self._h = handle
+        if not self.auto_reset:
+            _lib.check(self._L.marl_env_set_auto_reset(self._h, 0), "marl_env_set_auto_reset")
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -203,9 +210,13 @@ class BatchedOvercookedVecEnv:
 
     # ------------------------------------------------------------------
     def reset(self, seed=None, options=None, out=None, spawn_override=None, dir_override=None):
-        """agent_environment.py:34,88: every env restarts.  ``seed`` is accepted for API
-        compatibility and ignored (the reference never passes one; the key was fixed at
-        construction)."""
+        """agent_environment.py:34,88: every env restarts.  The reference never passes a seed;
+        when one is given the env RNG is re-keyed with it and its draw counters start over."""
+        if seed is not None:
+            torch.cuda.current_stream(self.device).synchronize()  # the old tables may still be in use
+            self.seed = int(seed)
+            self._create()
+            self.state.zero_()
         obs = self._new_obs(out)
         so, do = self._u8(spawn_override, "spawn_override"), self._u8(dir_override, "dir_override")
         _lib.check(self._L.marl_env_reset(self._h, _ptr(self.state), _ptr(obs), _ptr(so), _ptr(do), self._stream()),

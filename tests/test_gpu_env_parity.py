@@ -160,3 +160,49 @@ def test_single_env_dict_api_without_auto_reset(oracle_mod):
         done = [term[i] or trunc[i] for i in range(2)]
         assert all(done) == (t + 1 >= 12)       # stays done: nothing restarted the episode
     assert ora.misc[0, 0] == 15
+
+
+def test_determinism_and_reseeding():
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_coordination_ring_v0")
+    acts = torch.randint(0, 7, (30, 300 * 4), generator=torch.Generator().manual_seed(5))
+
+    def rollout(env):
+        outs = []
+        for t in range(30):
+            o, r, _, _, _ = env.step(acts[t])
+            outs.append((o[OBS_KEY].clone(), r.clone()))
+        return outs
+
+    a = BatchedOvercookedVecEnv(rows, 4, "local_obs", 300, max_steps=9, seed=1)
+    b = BatchedOvercookedVecEnv(rows, 4, "local_obs", 300, max_steps=9, seed=1)
+    c = BatchedOvercookedVecEnv(rows, 4, "local_obs", 300, max_steps=9, seed=2)
+    oa, ob, oc = a.reset()[0][OBS_KEY], b.reset()[0][OBS_KEY], c.reset()[0][OBS_KEY]
+    assert torch.equal(oa, ob) and not torch.equal(oa, oc)
+    ra, rb = rollout(a), rollout(b)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(ra, rb))
+    # re-keying c with seed 1 makes it replay a's episode from the start
+    oc2 = c.reset(seed=1)[0][OBS_KEY]
+    assert torch.equal(oc2, oa)
+    rc = rollout(c)
+    assert all(torch.equal(x[0], y[0]) for x, y in zip(ra, rc))
+
+
+def test_step_writes_into_caller_buffer_and_rejects_bad_ones():
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    env = BatchedOvercookedVecEnv(get_layout("overcooked_cramped_room_v0"), 2, "global_obs", 70, seed=3)
+    store = torch.zeros((3, env.N, env.D), device="cuda")
+    env.reset(out=store[0])
+    act = torch.randint(0, 7, (env.N,))
+    o, *_ = env.step(act, out=store[1])
+    assert o[OBS_KEY].data_ptr() == store[1].data_ptr()
+    assert store[2].abs().sum() == 0 and store[1].abs().sum() > 0
+    assert torch.equal(env.featurize(), store[1])
+    with pytest.raises(ValueError):
+        env.step(act, out=torch.zeros((env.N, env.D + 1), device="cuda")[:, :-1])   # not contiguous
+    with pytest.raises(ValueError):
+        env.step(act[:-1])
+    with pytest.raises(ValueError):
+        env.step(act, out=torch.zeros((env.N, env.D), dtype=torch.float64, device="cuda"))
