@@ -89,6 +89,40 @@ static void static_closest(const std::vector<uint8_t>& type, int W, int ncell, u
 
 static int align16(int x) { return (x + 15) & ~15; }
 
+// The PickupDrop rule chain, evaluated for every combination of the codes the kernel can meet:
+// pick up what lies loose on the floor / take from a stack / take from a counter / plate a
+// finished soup, otherwise, with something in hand: put it on an empty floor cell nobody
+// stands on, on an empty counter, an onion into a pot with room, a soup into the delivery
+// zone.  Rewards look at the state before the step: onion into a pot with room (0.1),
+// plate at a finished pot (0.3), soup at the delivery zone (1.0, shared).
+static void build_decision_tables(uint8_t* itab, uint8_t* rtab) {
+    for (uint32_t idx = 0; idx < (uint32_t)INT_TABLE_BYTES; ++idx) {
+        const uint32_t ct = idx & 7u, lying = (idx >> 3) & 3u, inv = (idx >> 5) & 3u, pst = (idx >> 7) & 3u;
+        const bool ahead = (idx >> 9) & 1u;
+        uint32_t ninv = inv, iop = INT_ITEM_KEEP, pop = INT_POT_KEEP;
+        const bool holder = ct == FLOOR || ct == COUNTER;
+        if (holder && lying != NONE && inv == NONE) { ninv = lying; iop = INT_ITEM_CLEAR; }
+        else if (ct == ONION_STACK && inv == NONE) ninv = ONION;
+        else if (ct == PLATE_STACK && inv == NONE) ninv = PLATE;
+        else if (ct == POT && inv == PLATE && pst == POTST_READY) { ninv = SOUP; pop = INT_POT_RESET; }
+        else if (inv != NONE) {
+            if (ct == FLOOR && lying == NONE) { if (!ahead) { ninv = NONE; iop = INT_ITEM_PUT; } }
+            else if (ct == COUNTER && lying == NONE) { ninv = NONE; iop = INT_ITEM_PUT; }
+            else if (ct == POT && inv == ONION && pst == POTST_ROOM) { ninv = NONE; pop = INT_POT_ADD; }
+            else if (ct == DELIVERY && inv == SOUP) ninv = NONE;
+        }
+        itab[idx] = (uint8_t)(ninv | (iop << 2) | (pop << 4));
+    }
+    for (uint32_t idx = 0; idx < (uint32_t)REW_TABLE_BYTES; ++idx) {
+        const uint32_t ct = idx & 7u, inv = (idx >> 3) & 3u, pst = (idx >> 5) & 3u;
+        uint32_t r = 0;
+        if (ct == POT && inv == ONION && pst == POTST_ROOM) r |= 1u;
+        if (ct == POT && inv == PLATE && pst == POTST_READY) r |= 2u;
+        if (ct == DELIVERY && inv == SOUP) r |= 4u;
+        rtab[idx] = (uint8_t)r;
+    }
+}
+
 static int build_tables(marl_env* env, const char* const* rows, int height, int dist_metric) {
     const int H = height;
     if (H <= 0 || rows == nullptr || rows[0] == nullptr) return fail(MARL_ERR_LAYOUT, "layout has no rows");
@@ -150,10 +184,13 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
     P.off_slotrc = off; off = align16(off + 128 * 2);  // full size: the "no slot" code may be looked up (result unused)
     P.off_potorder = off; off = align16(off + nfloor * 2);
     P.off_spawnf = off; off = align16(off + (int)spawn.size() + 1);
+    P.off_inttab = off; off = align16(off + INT_TABLE_BYTES);
+    P.off_rewtab = off; off = align16(off + REW_TABLE_BYTES);
     P.tab_bytes = off;
     env->tab.assign((size_t)off, 0);
     uint8_t* t = env->tab.data();
 
+    build_decision_tables(t + P.off_inttab, t + P.off_rewtab);
     uint32_t* nb = reinterpret_cast<uint32_t*>(t + P.off_nb);
     uint16_t* frc = reinterpret_cast<uint16_t*>(t + P.off_frc);
     uint16_t* slotrc = reinterpret_cast<uint16_t*>(t + P.off_slotrc);

@@ -114,9 +114,17 @@ __device__ __forceinline__ uint32_t pot_class(uint32_t pots, uint32_t p) {
     return c == 0 ? POT_EMPTY : c < (uint32_t)POT_CAPACITY ? POT_PARTIAL : t > 0 ? POT_COOKING : POT_READY;
 }
 
+// pot condition as the decision tables see it
+__device__ __forceinline__ uint32_t pot_state(uint32_t pots, uint32_t p) {
+    const uint32_t c = pot_count(pots, p), t = pot_timer(pots, p);
+    return c < (uint32_t)POT_CAPACITY ? POTST_ROOM : t > 0 ? POTST_COOKING : POTST_READY;
+}
+
 struct Lds {
     const uint8_t* b;
     const EnvParams& P;
+    __device__ __forceinline__ uint32_t int_entry(uint32_t idx) const { return b[P.off_inttab + idx]; }
+    __device__ __forceinline__ uint32_t rew_entry(uint32_t idx) const { return b[P.off_rewtab + idx]; }
     __device__ __forceinline__ uint4 nb(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_nb)[f]; }
     __device__ __forceinline__ uint32_t frc(uint32_t f) const {
         return reinterpret_cast<const uint16_t*>(b + P.off_frc)[f];
@@ -246,10 +254,7 @@ __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, cons
     }
 
     // ---- movement ----
-    uint32_t want[A], npos[A];
-    uint32_t movers = 0;  // packed 4-bit agent ids
-    uint32_t m = 0;
-    uint32_t decided = 0;
+    uint32_t want[A];
     static_for<0, A>([&](auto AI) {
         constexpr int a = AI.value;
         const bool is_move = act[a] < 4u;
@@ -258,120 +263,138 @@ __device__ __forceinline__ void step_env(EnvState<A, NIW>& s, const Lds& T, cons
         const uint32_t w = sel4(nb[a], d);
         const bool open = nb_type(w) == FLOOR && item_get<NIW>(s.items, nb_slot(w)) == NONE;
         want[a] = (is_move && open) ? nb_fidx(w) : s.f[a];
-        npos[a] = s.f[a];
-        const bool stays = want[a] == s.f[a];
-        decided |= stays ? (1u << a) : 0u;  // stayers keep their cell unconditionally
-        movers |= stays ? 0u : ((uint32_t)a << (4u * m));
-        m += stays ? 0u : 1u;
     });
-    if constexpr (A > 1) {
+    if constexpr (A == 2) {
+        // two agents: the general procedure below in closed form
+        const bool m0 = want[0] != s.f[0], m1 = want[1] != s.f[1];
+        const bool both = m0 && m1;
+        bool first1;  // agent 1 is served before agent 0
         if (prio) {
-            // replay mode: serve movers by ascending (rank, id)
-            uint32_t sorted = 0, left = 0;
-            static_for<0, A>([&](auto K) { if ((uint32_t)K.value < m) left |= 1u << ((movers >> (4 * K.value)) & 15u); });
-            static_for<0, A>([&](auto K) {
-                if ((uint32_t)K.value < m) {
-                    uint32_t best = 0xFFFFFFFFu;
-                    static_for<0, A>([&](auto AI) {
-                        if (left & (1u << AI.value))
-                            best = min(best, ((uint32_t)prio[(size_t)e * A + AI.value] << 4) | (uint32_t)AI.value);
-                    });
-                    sorted |= (best & 15u) << (4 * K.value);
-                    left &= ~(1u << (best & 15u));
-                }
-            });
-            movers = sorted;
+            first1 = both && prio[(size_t)e * 2 + 1] < prio[(size_t)e * 2];
         } else {
-            // Fisher-Yates on the packed list, i = m-1 .. 1
-            static_for<1, A>([&](auto K) {
-                constexpr int i = A - K.value;  // A-1 .. 1
-                const bool on = (uint32_t)i < m;
-                const uint32_t j = s.rng.below(i + 1, on);
-                const uint32_t x = on ? (((movers >> (4 * i)) ^ (movers >> (4 * j))) & 15u) : 0u;
-                movers ^= (x << (4 * i)) | (x << (4 * j));
+            const uint32_t j = s.rng.below(2, both);  // Fisher-Yates step i = 1: swap when j == 0
+            first1 = both && j == 0;
+        }
+        uint32_t n0 = want[0], n1 = want[1];
+        // a lone mover may not enter the cell its partner keeps
+        n0 = (m0 && !m1 && want[0] == s.f[1]) ? s.f[0] : n0;
+        n1 = (m1 && !m0 && want[1] == s.f[0]) ? s.f[1] : n1;
+        // same target: whoever is served second stays
+        const bool same = both && want[0] == want[1];
+        n0 = (same && first1) ? s.f[0] : n0;
+        n1 = (same && !first1) ? s.f[1] : n1;
+        // no passing through each other
+        const bool swap = both && want[0] == s.f[1] && want[1] == s.f[0];
+        s.f[0] = swap ? s.f[0] : n0;
+        s.f[1] = swap ? s.f[1] : n1;
+    } else {
+        uint32_t npos[A];
+        uint32_t movers = 0;  // packed 4-bit agent ids
+        uint32_t m = 0;
+        uint32_t decided = 0;
+        static_for<0, A>([&](auto AI) {
+            constexpr int a = AI.value;
+            npos[a] = s.f[a];
+            const bool stays = want[a] == s.f[a];
+            decided |= stays ? (1u << a) : 0u;  // stayers keep their cell unconditionally
+            movers |= stays ? 0u : ((uint32_t)a << (4u * m));
+            m += stays ? 0u : 1u;
+        });
+        if constexpr (A > 1) {
+            if (prio) {
+                // replay mode: serve movers by ascending (rank, id)
+                uint32_t sorted = 0, left = 0;
+                static_for<0, A>([&](auto K) { if ((uint32_t)K.value < m) left |= 1u << ((movers >> (4 * K.value)) & 15u); });
+                static_for<0, A>([&](auto K) {
+                    if ((uint32_t)K.value < m) {
+                        uint32_t best = 0xFFFFFFFFu;
+                        static_for<0, A>([&](auto AI) {
+                            if (left & (1u << AI.value))
+                                best = min(best, ((uint32_t)prio[(size_t)e * A + AI.value] << 4) | (uint32_t)AI.value);
+                        });
+                        sorted |= (best & 15u) << (4 * K.value);
+                        left &= ~(1u << (best & 15u));
+                    }
+                });
+                movers = sorted;
+            } else {
+                // Fisher-Yates on the packed list, i = m-1 .. 1
+                static_for<1, A>([&](auto K) {
+                    constexpr int i = A - K.value;  // A-1 .. 1
+                    const bool on = (uint32_t)i < m;
+                    const uint32_t j = s.rng.below(i + 1, on);
+                    const uint32_t x = on ? (((movers >> (4 * i)) ^ (movers >> (4 * j))) & 15u) : 0u;
+                    movers ^= (x << (4 * i)) | (x << (4 * j));
+                });
+            }
+        }
+        static_for<0, A>([&](auto K) {
+            const bool on = (uint32_t)K.value < m;
+            const uint32_t a = (movers >> (4 * K.value)) & 15u;
+            const uint32_t wa = pick<A>(want, a);
+            bool taken = false;
+            static_for<0, A>([&](auto B) { taken |= ((decided >> B.value) & 1u) && npos[B.value] == wa; });
+            static_for<0, A>([&](auto B) {
+                npos[B.value] = (on && a == (uint32_t)B.value && !taken) ? wa : npos[B.value];
+            });
+            decided |= on ? (1u << a) : 0u;
+        });
+        // no passing through each other
+        static_for<0, A>([&](auto AI) {
+            static_for<AI.value + 1, A>([&](auto BI) {
+                constexpr int a = AI.value, b = BI.value;
+                const bool swap = npos[a] == s.f[b] && npos[b] == s.f[a] && npos[a] != s.f[a];
+                npos[a] = swap ? s.f[a] : npos[a];
+                npos[b] = swap ? s.f[b] : npos[b];
+            });
+        });
+        // three or more agents: whoever moved onto a cell somebody was left standing on goes back
+        if constexpr (A > 2) {
+            static_for<0, A>([&](auto) {
+                static_for<0, A>([&](auto AI) {
+                    constexpr int a = AI.value;
+                    bool clash = false;
+                    static_for<0, A>([&](auto BI) { if (BI.value != a) clash |= npos[BI.value] == npos[a]; });
+                    npos[a] = (clash && npos[a] != s.f[a]) ? s.f[a] : npos[a];
+                });
             });
         }
+        static_for<0, A>([&](auto K) { s.f[K.value] = npos[K.value]; });
     }
-    static_for<0, A>([&](auto K) {
-        const bool on = (uint32_t)K.value < m;
-        const uint32_t a = (movers >> (4 * K.value)) & 15u;
-        const uint32_t wa = pick<A>(want, a);
-        bool taken = false;
-        static_for<0, A>([&](auto B) { taken |= ((decided >> B.value) & 1u) && npos[B.value] == wa; });
-        static_for<0, A>([&](auto B) {
-            npos[B.value] = (on && a == (uint32_t)B.value && !taken) ? wa : npos[B.value];
-        });
-        decided |= on ? (1u << a) : 0u;
-    });
-    // no passing through each other
-    static_for<0, A>([&](auto AI) {
-        static_for<AI.value + 1, A>([&](auto BI) {
-            constexpr int a = AI.value, b = BI.value;
-            const bool swap = npos[a] == s.f[b] && npos[b] == s.f[a] && npos[a] != s.f[a];
-            npos[a] = swap ? s.f[a] : npos[a];
-            npos[b] = swap ? s.f[b] : npos[b];
-        });
-    });
-    // three or more agents: whoever moved onto a cell somebody was left standing on goes back
-    if constexpr (A > 2) {
-        static_for<0, A>([&](auto) {
-            static_for<0, A>([&](auto AI) {
-                constexpr int a = AI.value;
-                bool clash = false;
-                static_for<0, A>([&](auto BI) { if (BI.value != a) clash |= npos[BI.value] == npos[a]; });
-                npos[a] = (clash && npos[a] != s.f[a]) ? s.f[a] : npos[a];
-            });
-        });
-    }
-    static_for<0, A>([&](auto K) { s.f[K.value] = npos[K.value]; });
 
     // ---- interact (agent-id order) and reward conditions (previous state) ----
     // A PickupDrop agent neither moved nor turned, so the neighbour words loaded above are
-    // still those of its cell and its front cell is also its previous front cell.
+    // still those of its cell and its front cell is also its previous front cell.  What happens
+    // is a pure function of a handful of small codes -- front cell type, what lies there, what
+    // the agent holds, the pot's condition, whether another agent stands there -- so the rule
+    // chain is evaluated once on the host into two byte tables (csrc/capi.hip) and each agent's
+    // interaction here is one LDS lookup.  Codes that do not apply to a cell type (the pot
+    // condition of a counter, ...) index identical entries, so they need no masking.
     onion_mask = dish_mask = deliver_mask = 0;
     static_for<0, A>([&](auto AI) {
         constexpr int a = AI.value;
         const bool on = act[a] == ACT_PICKUP_DROP;
         const uint32_t w = sel4(nb[a], s.dir[a]);
         const uint32_t ct = nb_type(w), slot = nb_slot(w), p = nb_pot(w), nf = nb_fidx(w);
-        const bool holds_items = (ct == FLOOR || ct == COUNTER);
-        const uint32_t lying = holds_items ? item_get<NIW>(s.items, slot) : (uint32_t)NONE;
-        const bool is_pot = ct == POT;
-
-        const uint32_t ppc = pot_count(prev_pots, p), ppt = pot_timer(prev_pots, p);
-        onion_mask |= (on && is_pot && prev_inv[a] == ONION && ppc < (uint32_t)POT_CAPACITY) ? (1u << a) : 0u;
-        dish_mask |= (on && is_pot && prev_inv[a] == PLATE && ppc == (uint32_t)POT_CAPACITY && ppt == 0) ? (1u << a) : 0u;
-        deliver_mask |= (on && ct == DELIVERY && prev_inv[a] == SOUP) ? (1u << a) : 0u;
-
-        bool ahead = false;
-        static_for<0, A>([&](auto BI) { if (BI.value != a) ahead |= s.f[BI.value] == nf; });
-        ahead = ahead && ct == FLOOR;
-
+        const uint32_t lying = item_get<NIW>(s.items, slot);
         const uint32_t inv = s.inv[a];
-        const uint32_t pc = pot_count(s.pots, p), pt = pot_timer(s.pots, p);
-        const bool empty_hand = inv == NONE;
-        const bool c_pick = on && holds_items && lying != NONE && empty_hand;
-        const bool c_onion = on && ct == ONION_STACK && empty_hand;
-        const bool c_plate = on && ct == PLATE_STACK && empty_hand;
-        const bool c_soup = on && is_pot && inv == PLATE && pc == (uint32_t)POT_CAPACITY && pt == 0;
-        const bool took = c_pick || c_onion || c_plate || c_soup;
-        const bool may_drop = on && !took && !empty_hand;
-        const bool c_dropf = may_drop && ct == FLOOR && lying == NONE && !ahead;
-        const bool c_dropc = may_drop && ct == COUNTER && lying == NONE;
-        const bool c_pot = may_drop && is_pot && inv == ONION && pc < (uint32_t)POT_CAPACITY;
-        const bool c_deliv = may_drop && ct == DELIVERY && inv == SOUP;
 
-        uint32_t ninv = inv;
-        ninv = (c_dropf || c_dropc || c_pot || c_deliv) ? (uint32_t)NONE : ninv;
-        ninv = c_soup ? (uint32_t)SOUP : ninv;
-        ninv = c_plate ? (uint32_t)PLATE : ninv;
-        ninv = c_onion ? (uint32_t)ONION : ninv;
-        ninv = c_pick ? lying : ninv;
-        s.inv[a] = ninv;
-        item_set<NIW>(s.items, slot, c_pick ? (uint32_t)NONE : inv, c_pick || c_dropf || c_dropc);
+        const uint32_t rent = T.rew_entry(ct | (prev_inv[a] << 3) | (pot_state(prev_pots, p) << 5));
+        onion_mask |= on ? ((rent & 1u) << a) : 0u;
+        dish_mask |= on ? (((rent >> 1) & 1u) << a) : 0u;
+        deliver_mask |= on ? (((rent >> 2) & 1u) << a) : 0u;
+
+        uint32_t ahead = 0;
+        static_for<0, A>([&](auto BI) { if (BI.value != a) ahead |= (s.f[BI.value] == nf) ? 1u : 0u; });
+
+        const uint32_t looked = T.int_entry(ct | (lying << 3) | (inv << 5) | (pot_state(s.pots, p) << 7) | (ahead << 9));
+        const uint32_t ent = on ? looked : inv;  // new holding | item op << 2 | pot op << 4
+        const uint32_t iop = (ent >> 2) & 3u, pop = (ent >> 4) & 3u;
+        s.inv[a] = ent & 3u;
+        item_set<NIW>(s.items, slot, iop == INT_ITEM_CLEAR ? (uint32_t)NONE : inv, iop != INT_ITEM_KEEP);
         const uint32_t pbyte = 0xFFu << (8u * p);
-        s.pots = c_soup ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
-        s.pots += c_pot ? (1u << (8u * p)) : 0u;
+        s.pots = pop == INT_POT_RESET ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
+        s.pots += pop == INT_POT_ADD ? (1u << (8u * p)) : 0u;
     });
 }
 
@@ -663,19 +686,39 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         const uint32_t nfloat = (uint32_t)(rows_here * D);
         const uint32_t nchunk = nfloat / 4;  // 64*D is a multiple of 4; the tail of a short last group is handled below
         const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
-        float* out = obs + row0 * D;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, nchunk * 16u, 0x00020000);
+        // the descriptor must be provably wave-uniform (scalar registers), or every store is
+        // wrapped in a lane-by-lane loop: the wave index comes from threadIdx, so say it explicitly
+        const uint64_t out_bits = reinterpret_cast<uint64_t>(obs + row0 * D);
+        // (the builtin returns a signed int: widen through uint32_t or the low half's top bit
+        // smears over the high half of the address)
+        const uint32_t out_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)out_bits);
+        const uint32_t out_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(out_bits >> 32));
+        float* out = reinterpret_cast<float*>(((uint64_t)out_hi << 32) | (uint64_t)out_lo);
+        const uint32_t nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nchunk * 16u));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, nbytes, 0x00020000);
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        for (uint32_t q = lane; q < nchunk; q += 64) {
-            const uint32_t v = img32[q];
+        // Fully unrolled: iteration k handles chunk k*64 + lane, so the LDS address and the store
+        // offset are the lane's base plus compile-time constants and the loop costs no address
+        // arithmetic.  Chunks past the end of a short last group are dropped by the descriptor's
+        // range check (their LDS reads return whatever lies there; it is never stored).  The
+        // constant goes into the VECTOR offset: the range check covers the vector offset plus
+        // the 12-bit instruction offset but NOT the scalar offset operand, so a constant passed
+        // there would let the tail lanes write past the group's rows.  The compiler splits the
+        // sum into a multiple of 4096 (one add per four iterations) and the instruction offset.
+        constexpr int ITERS = (16 * D + 63) / 64;
+        const uint32_t* my = img32 + lane;
+        const uint32_t voff = (uint32_t)lane * 16u;
+        static_for<0, ITERS>([&](auto K) {
+            constexpr int k = K.value;
+            const uint32_t v = my[k * 64];
             f32x4 f;
             f.x = (float)(int)(int8_t)(v);
             f.y = (float)(int)(int8_t)(v >> 8);
             f.z = (float)(int)(int8_t)(v >> 16);
             f.w = (float)(int)(int8_t)(v >> 24);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, q * 16u, 0, OC_STORE_AUX);
-        }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, voff + (uint32_t)(k * 1024), 0, OC_STORE_AUX);
+        });
         // a short last group can leave up to 3 floats past the last full chunk
         const uint32_t rem = nfloat & 3u;
         if (rem && lane < (int)rem) {

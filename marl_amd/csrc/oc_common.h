@@ -86,6 +86,17 @@ inline uint32_t nb_pack(uint32_t type, uint32_t slot, uint32_t pot, uint32_t fid
     return type | (slot << 3) | (pot << 10) | (fidx << 16);
 }
 
+// ---- decision tables of the interact rule chain (built once on the host) ----
+// interact table, 1024 bytes, index = type | lying << 3 | holding << 5 | pot state << 7 | agent ahead << 9
+//   entry = new holding | item op << 2 | pot op << 4
+// reward table, 128 bytes, index = type | holding before the step << 3 | pot state before the step << 5
+//   entry = onion_in_pot | soup_in_dish << 1 | delivery << 2
+enum : uint32_t { POTST_ROOM = 0, POTST_COOKING = 1, POTST_READY = 2 };
+enum : uint32_t { INT_ITEM_KEEP = 0, INT_ITEM_CLEAR = 1, INT_ITEM_PUT = 2 };
+enum : uint32_t { INT_POT_KEEP = 0, INT_POT_ADD = 1, INT_POT_RESET = 2 };
+constexpr int INT_TABLE_BYTES = 1024;
+constexpr int REW_TABLE_BYTES = 128;
+
 // ---- hot lookup blob, indexed by FLOOR INDEX (agents only ever stand on floor cells) ----
 // All offsets are multiples of 16 bytes and live in EnvParams.
 //   nb       uint32[nfloor][4]     neighbour words in direction order (right, down, left, up)
@@ -94,6 +105,7 @@ inline uint32_t nb_pack(uint32_t type, uint32_t slot, uint32_t pot, uint32_t fid
 //   slotrc   uint16[nslots]        (row << 8) | col of each item slot (slots are in row-major cell order)
 //   potorder uint8[nfloor][2]      the two nearest pots (0xFF = none)
 //   spawnf   uint8[nspawn]         floor indices of the '+' cells
+//   inttab   uint8[1024], rewtab uint8[128]   the decision tables above
 struct EnvParams {
     int E;            // envs in this shard
     int NP;           // pots
@@ -104,7 +116,7 @@ struct EnvParams {
     int tab_bytes;    // size of the hot blob, multiple of 16
     int dist_metric;  // 0 = L1, 1 = squared L2
     int auto_reset;   // 1: a truncated env restarts inside the step (vector-env semantics)
-    int off_nb, off_postab, off_frc, off_slotrc, off_potorder, off_spawnf;
+    int off_nb, off_postab, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab;
     uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard
 };
