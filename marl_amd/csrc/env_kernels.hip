@@ -20,6 +20,14 @@
 // overcooked_features.py:38-78,107-130 (one block per agent; own block first, then the
 // others in agent-id order).
 #include <hip/hip_runtime.h>
+// Profiling aid: with -DOC_STAMPS the priority-override argument is taken as a uint64 buffer
+// [waves][10] that receives each wave's cycle counter after every phase (no override then).
+#ifdef OC_STAMPS
+#define OC_STAMP(k) stamp[k] = __builtin_readcyclecounter()
+#else
+#define OC_STAMP(k)
+#endif
+
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -28,12 +36,11 @@
 #include "oc_common.h"
 
 // Cache policy of the observation stores (buffer-instruction aux bits on gfx950: 1 = sc0,
-// 2 = nt, 16 = sc1).  sc1 = write-through: the 106 MB a launch writes do not stay dirty in the
-// XCD L2s, so the end-of-kernel write-back has nothing left to flush.  Measured on the headline
-// config: plain 21.5 us, nt 25.3 us, sc1 20.1 us per launch.
-#ifndef OC_STORE_AUX
-#define OC_STORE_AUX 16
-#endif
+// 2 = nt, 16 = sc1).  sc1 = write-through: what a launch writes does not stay dirty in the
+// XCD L2s, so the end-of-kernel write-back has nothing left to flush.  Measured per launch on
+// cramped_room, 2 agents, global_obs: 65,536 envs (106 MB of rows) plain 20.3 us, nt 23.8,
+// sc1 19.3, sc1+nt 23.6; 262,144 envs (424 MB) plain 85.3 us, nt 82.7, sc1 83.3, sc1+nt 79.5.
+constexpr int STORE_NT = 2, STORE_SC1 = 16;
 
 namespace oc {
 
@@ -610,6 +617,12 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     const uint32_t i = (uint32_t)(row % A);
     const int ablate = mode >> 8;  // 1 = skip the store stream, 2 = skip the simulation (timing only)
     mode &= 0xFF;
+#ifdef OC_STAMPS
+    uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t* stamp_out = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(prio));
+    prio = nullptr;
+    OC_STAMP(0);
+#endif
 
     // issue the HBM reads first so that they fly while the lookup blob is staged
     uint32_t raw[NRAW];
@@ -629,6 +642,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         for (int k = threadIdx.x; k < P.tab_bytes / 16; k += blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
+    OC_STAMP(1);
     Lds T{smem, P};
     uint8_t* img = smem + P.tab_bytes + wave * (64 * D);
 
@@ -640,9 +654,11 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             const uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
             s.rng.key = mix32(k ^ (uint32_t)(g >> 32));
         }
+        OC_STAMP(2);
         if (mode == 0) {
             uint32_t onion_mask, dish_mask, deliver_mask;
             step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
+            OC_STAMP(3);
             // rewards accumulate as Python floats in the config's list order
             // [onion_in_pot 0.1, soup_in_dish 0.3, delivery 1.0 shared] (overcooked_config.py:96)
             double r = 0.0;
@@ -662,8 +678,10 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             if (i == 0) store_state<A, NIW>(s, state, P.E, e);
         }
 
+        OC_STAMP(4);
         Block<NW> blk;
         build_block<A, FEAT, NIW>(blk, s, T, P, i);
+        OC_STAMP(5);
         if constexpr (FEAT == FEAT_GLOBAL) {
             // my block goes into every row of my env: first in my own, after the lower ids elsewhere
             const uint32_t env_lane0 = (uint32_t)lane - i;
@@ -676,7 +694,13 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             write_block<BLK, NW>(img, (uint32_t)lane * D, blk.w);
         }
     }
-    __syncthreads();
+    OC_STAMP(6);
+    // A wave's row image is written and read by that wave alone (the A lanes of an env share a
+    // wave), and LDS operations of one wave complete in order: ordering within the wave is
+    // all that is needed, so waves of a workgroup start streaming as soon as they are done.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // stream the wave's rows out: 4 int8 -> 4 floats -> one 16-byte store per lane.  The stores
     // go through a wave-uniform buffer descriptor over exactly this wave's rows (the hardware
@@ -709,16 +733,25 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         constexpr int ITERS = (16 * D + 63) / 64;
         const uint32_t* my = img32 + lane;
         const uint32_t voff = (uint32_t)lane * 16u;
-        static_for<0, ITERS>([&](auto K) {
-            constexpr int k = K.value;
-            const uint32_t v = my[k * 64];
-            f32x4 f;
-            f.x = (float)(int)(int8_t)(v);
-            f.y = (float)(int)(int8_t)(v >> 8);
-            f.z = (float)(int)(int8_t)(v >> 16);
-            f.w = (float)(int)(int8_t)(v >> 24);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, voff + (uint32_t)(k * 1024), 0, OC_STORE_AUX);
-        });
+        // Cache policy of the stores (measured on MI355X): below the size of the last-level
+        // cache a write-through-to-system-scope store (sc1) is fastest, the rows then sit in
+        // that cache for the consumer; a larger observation tensor streams to HBM and does
+        // better with the non-temporal hint added.  The host picks by tensor size.
+        auto stream = [&](auto AUX) {
+            static_for<0, ITERS>([&](auto K) {
+                constexpr int k = K.value;
+                const uint32_t v = my[k * 64];
+                f32x4 f;
+                f.x = (float)(int)(int8_t)(v);
+                f.y = (float)(int)(int8_t)(v >> 8);
+                f.z = (float)(int)(int8_t)(v >> 16);
+                f.w = (float)(int)(int8_t)(v >> 24);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, voff + (uint32_t)(k * 1024), 0,
+                                                       decltype(AUX)::value);
+            });
+        };
+        if (P.stream_nt) stream(std::integral_constant<int, STORE_SC1 | STORE_NT>{});
+        else stream(std::integral_constant<int, STORE_SC1>{});
         // a short last group can leave up to 3 floats past the last full chunk
         const uint32_t rem = nfloat & 3u;
         if (rem && lane < (int)rem) {
@@ -726,6 +759,15 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             out[idx] = (float)(int)(int8_t)img[idx];
         }
     }
+#ifdef OC_STAMPS
+    OC_STAMP(7);
+    if (stamp_out && lane == 0) {
+        uint64_t* o = stamp_out + (row0 / 64) * 10;
+        static_for<0, 8>([&](auto K) { o[K.value] = stamp[K.value]; });
+        o[8] = wall_clock64();
+        o[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -739,8 +781,8 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     using G = FeatGeom<A, FEAT>;
     // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
     static const int waves_req = [] { const char* v = getenv("MARL_AMD_WAVES"); return v ? atoi(v) : 4; }();  // tuning aid
-    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4) ? waves_req : 4;
-    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * 64 * G::D > 64 * 1024) waves >>= 1;
+    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4 || waves_req == 8) ? waves_req : 4;
+    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * 64 * G::D > (waves_req == 8 ? 128 : 64) * 1024) waves >>= 1;
     const size_t lds = (size_t)P.tab_bytes + (size_t)waves * 64 * G::D;
     static size_t configured[64] = {0};  // per instantiation and device
     int dev = 0;

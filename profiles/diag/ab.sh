@@ -1,5 +1,6 @@
-# A/B the cache-policy variants of the obs store stream in separate bench runs (same box)
+# A/B diagnostic variants of the library in separate bench runs on the same box: "name[:waves]" ...
 for rep in 1 2; do
-for aux in 0 2 16 17 18; do
-  MARL_AMD_LIB=$PWD/profiles/diag/libvar_$aux.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 4096 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('aux=$aux us_per_launch=%.2f frac=%.3f' % (d['roofline']['us_per_launch'], d['roofline']['frac']))" || exit 1
+for spec in "$@"; do
+  name=${spec%%:*}; w=${spec#*:}; [ "$w" = "$spec" ] && w=4
+  MARL_AMD_WAVES=$w MARL_AMD_LIB=$PWD/profiles/diag/libvar_$name.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 4096 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name waves=$w us_per_launch=%.2f frac=%.3f' % (d['roofline']['us_per_launch'], d['roofline']['frac']))" || exit 1
 done; done

@@ -137,6 +137,30 @@ def test_full_size_properties():
     assert torch.equal(ow[OBS_KEY], ow[OBS_KEY].round())
 
 
+def test_store_policy_does_not_change_rows(monkeypatch):
+    """Large observation tensors are stored with a different cache hint; force each policy on the
+    same small job (ragged last row group included) and compare every output."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    outs = []
+    for nt in ("0", "1"):
+        monkeypatch.setenv("MARL_AMD_STREAM_NT", nt)
+        for layout, A, feat, E in (("overcooked_cramped_room_v0", 2, "global_obs", 1000),
+                                   ("overcooked_coordination_ring_v0", 4, "local_obs", 333)):
+            env = BatchedOvercookedVecEnv(get_layout(layout), A, feat, E, max_steps=25, seed=3)
+            g = torch.Generator(device="cpu").manual_seed(1)
+            o, _ = env.reset()
+            got = [o[OBS_KEY].clone()]
+            for _ in range(40):
+                o, r, _, tr, _ = env.step(torch.randint(0, 7, (E * A,), generator=g))
+                got += [o[OBS_KEY].clone(), r.clone(), tr.clone()]
+            outs.append(got)
+    half = len(outs) // 2
+    for a, b in zip(outs[:half], outs[half:]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_single_env_dict_api_without_auto_reset(oracle_mod):
     """make_env(...) itself steps like a bare cogrid env (tests/test_load.py:74-79,104-128):
     per-agent dicts, and no restart inside step()."""
