@@ -180,6 +180,7 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
     int off = 0;
     P.off_nb = off; off = align16(off + nfloor * 16);
     P.off_postab = off; off = align16(off + nfloor * NWP * 4);
+    P.off_adj = off; off = align16(off + nfloor * 32);
     P.off_frc = off; off = align16(off + nfloor * 2);
     P.off_slotrc = off; off = align16(off + 128 * 2);  // full size: the "no slot" code may be looked up (result unused)
     P.off_potorder = off; off = align16(off + nfloor * 2);
@@ -213,6 +214,13 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
             const uint32_t pot = pot_of_cell[c] < 0 ? NB_NO_POT : (uint32_t)pot_of_cell[c];
             const uint32_t fi = type[c] == FLOOR ? aux[AUX_FIDX_OF_CELL + c] : 0u;
             nb[4 * k + d] = nb_pack(type[c], slot, pot, fi);
+        }
+        uint32_t* adj = reinterpret_cast<uint32_t*>(t + P.off_adj) + 8 * k;
+        for (int j = 0; j < 4; ++j) {
+            const int c = (ar + adj_dr[j]) * W + ac + adj_dc[j];
+            if (pot_of_cell[c] >= 0) adj[pot_of_cell[c]] |= 1u << (8 * j);
+            if (type[c] == FLOOR) adj[4] |= 1u << (8 * j);
+            adj[5] |= (aux[AUX_SLOT_OF_CELL + c] == 0xFF ? NB_NO_SLOT : (uint32_t)aux[AUX_SLOT_OF_CELL + c]) << (8 * j);
         }
         int8_t* blk = reinterpret_cast<int8_t*>(t + P.off_postab) + (size_t)k * NWP * 4;
         // nearest pots, used by the kernel for the dynamic pot fields as well

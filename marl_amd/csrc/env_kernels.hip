@@ -133,6 +133,8 @@ struct Lds {
     __device__ __forceinline__ uint32_t int_entry(uint32_t idx) const { return b[P.off_inttab + idx]; }
     __device__ __forceinline__ uint32_t rew_entry(uint32_t idx) const { return b[P.off_rewtab + idx]; }
     __device__ __forceinline__ uint4 nb(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_nb)[f]; }
+    __device__ __forceinline__ uint4 pot_adj(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_adj)[2 * f]; }
+    __device__ __forceinline__ uint4 adj_info(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_adj)[2 * f + 1]; }
     __device__ __forceinline__ uint32_t frc(uint32_t f) const {
         return reinterpret_cast<const uint16_t*>(b + P.off_frc)[f];
     }
@@ -489,26 +491,43 @@ __device__ __forceinline__ void build_block(Block<FeatGeom<A, FEAT>::NW>& blk, c
         const uint32_t rc = T.frc(myf);
         const int ar = (int)(rc >> 8), ac = (int)(rc & 0xFFu);
 
-        // NextToPot (4 status rows x 4 adjacency columns) and CanMoveDirection; adjacency order
-        // right, left, down, up (pinned by the reference's golden vector) = directions 0, 2, 1, 3
-        const uint4 me = T.nb(myf);
+        // NextToPot (4 status rows x 4 adjacency columns; adjacency order right, left, down, up,
+        // pinned by the reference's golden vector).  Which neighbours are which pot is static:
+        // the table holds, per floor cell and pot, the four adjacency bytes; a pot's condition
+        // only picks the row they go to.
+        const uint4 pa = T.pot_adj(myf);
         uint32_t ntp[4] = {0u, 0u, 0u, 0u};
-        uint32_t can_move = 0;
-        static_for<0, 4>([&](auto K) {
-            constexpr int k = K.value;
-            const uint32_t w = k == 0 ? me.x : k == 1 ? me.z : k == 2 ? me.y : me.w;
-            const uint32_t ct = nb_type(w);
-            const uint32_t row = (NEXT_TO_POT_ROW_PACKED >> (4 * pot_class(s.pots, nb_pot(w)))) & 3u;
-            static_for<0, 4>([&](auto R) { ntp[R.value] |= (ct == POT && row == (uint32_t)R.value) ? (1u << (8 * k)) : 0u; });
-            can_move |= (ct == FLOOR && item_get<NIW>(s.items, nb_slot(w)) == NONE) ? (1u << (8 * k)) : 0u;
+        static_for<0, MAX_POTS>([&](auto PI) {
+            constexpr int p = PI.value;
+            if (p < P.NP) {
+                const uint32_t row = (NEXT_TO_POT_ROW_PACKED >> (4 * pot_class(s.pots, p))) & 3u;
+                const uint32_t m = p == 0 ? pa.x : p == 1 ? pa.y : p == 2 ? pa.z : pa.w;
+                static_for<0, 4>([&](auto R) { ntp[R.value] |= row == (uint32_t)R.value ? m : 0u; });
+            }
         });
         blk.template put4<G::O_NEXT_POT + 0>(ntp[0]);
         blk.template put4<G::O_NEXT_POT + 4>(ntp[1]);
         blk.template put4<G::O_NEXT_POT + 8>(ntp[2]);
         blk.template put4<G::O_NEXT_POT + 12>(ntp[3]);
-        blk.template put4<G::O_CAN_MOVE>(can_move);
 
-        if constexpr (G::kOthers && A > 1) {
+        // CanMoveDirection: the neighbour is floor (static byte mask) and nothing lies on it
+        const uint4 ad = T.adj_info(myf);  // x = floor mask, y = item slot of each neighbour
+        uint32_t occ[NIW];
+        static_for<0, NIW>([&](auto K) { occ[K.value] = (s.items[K.value] | (s.items[K.value] >> 1)) & 0x55555555u; });
+        uint32_t busy = 0;
+        static_for<0, 4>([&](auto K) {
+            constexpr int k = K.value;
+            const uint32_t sl = (ad.y >> (8 * k)) & 0xFFu;
+            const uint32_t word = pick<NIW>(occ, sl >> 4);
+            busy |= ((word >> ((sl & 15u) * 2u)) & 1u) << (8 * k);
+        });
+        blk.template put4<G::O_CAN_MOVE>(ad.x & ~busy);
+
+        if constexpr (G::kOthers && A == 2) {
+            const uint32_t orc = T.frc(i ? s.f[0] : s.f[1]);
+            blk.template put4<G::O_OTHERS>(((uint32_t)(ar - (int)(orc >> 8)) & 0xFFu) |
+                                           (((uint32_t)(ac - (int)(orc & 0xFFu)) & 0xFFu) << 8));
+        } else if constexpr (G::kOthers && A > 2) {
             // (self - other) for the other agents in id order: pair j sits at byte 2j
             uint32_t lo = 0, hi = 0;
             static_for<0, A>([&](auto BI) {

@@ -101,6 +101,9 @@ constexpr int REW_TABLE_BYTES = 128;
 // All offsets are multiples of 16 bytes and live in EnvParams.
 //   nb       uint32[nfloor][4]     neighbour words in direction order (right, down, left, up)
 //   postab   uint32[nfloor][NWP]   static part of the feature block of an agent standing there
+//   adj      uint32[nfloor][8]     [0..3] per pot: byte k = 1 where neighbour k is that pot; [4] byte k = 1
+//                                  where neighbour k is floor; [5] byte k = item slot of neighbour k
+//                                  (neighbour order right, left, down, up)
 //   frc      uint16[nfloor]        (row << 8) | col of the floor cell
 //   slotrc   uint16[nslots]        (row << 8) | col of each item slot (slots are in row-major cell order)
 //   potorder uint8[nfloor][2]      the two nearest pots (0xFF = none)
@@ -117,7 +120,7 @@ struct EnvParams {
     int dist_metric;  // 0 = L1, 1 = squared L2
     int auto_reset;   // 1: a truncated env restarts inside the step (vector-env semantics)
     int stream_nt;    // 1: observation rows exceed the last-level cache, store them non-temporally
-    int off_nb, off_postab, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab;
+    int off_nb, off_postab, off_adj, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab;
     uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard
 };
