@@ -118,13 +118,18 @@ __device__ __forceinline__ uint32_t pot_count(uint32_t pots, uint32_t p) { retur
 __device__ __forceinline__ uint32_t pot_timer(uint32_t pots, uint32_t p) { return (pots >> (8u * p + 2u)) & 31u; }
 __device__ __forceinline__ uint32_t pot_class(uint32_t pots, uint32_t p) {
     const uint32_t c = pot_count(pots, p), t = pot_timer(pots, p);
-    return c == 0 ? POT_EMPTY : c < (uint32_t)POT_CAPACITY ? POT_PARTIAL : t > 0 ? POT_COOKING : POT_READY;
+    // branch-free: the nested conditional compiles to divergent control flow otherwise
+    static_assert(POT_EMPTY == 0 && POT_PARTIAL == 1 && POT_COOKING == 2 && POT_READY == 3, "class codes");
+    const uint32_t filling = min(c, 1u);            // empty 0, partial 1
+    const uint32_t full = 3u - min(t, 1u);          // cooking 2, ready 3
+    return c == (uint32_t)POT_CAPACITY ? full : filling;
 }
 
 // pot condition as the decision tables see it
 __device__ __forceinline__ uint32_t pot_state(uint32_t pots, uint32_t p) {
     const uint32_t c = pot_count(pots, p), t = pot_timer(pots, p);
-    return c < (uint32_t)POT_CAPACITY ? POTST_ROOM : t > 0 ? POTST_COOKING : POTST_READY;
+    static_assert(POTST_ROOM == 0 && POTST_COOKING == 1 && POTST_READY == 2, "state codes");
+    return c == (uint32_t)POT_CAPACITY ? 2u - min(t, 1u) : 0u;
 }
 
 struct Lds {
@@ -500,7 +505,8 @@ __device__ __forceinline__ void build_block(Block<FeatGeom<A, FEAT>::NW>& blk, c
         static_for<0, MAX_POTS>([&](auto PI) {
             constexpr int p = PI.value;
             if (p < P.NP) {
-                const uint32_t row = (NEXT_TO_POT_ROW_PACKED >> (4 * pot_class(s.pots, p))) & 3u;
+                static_assert(NEXT_TO_POT_ROW_PACKED == 0x3210, "row of a class is the class code itself");
+                const uint32_t row = pot_class(s.pots, p);
                 const uint32_t m = p == 0 ? pa.x : p == 1 ? pa.y : p == 2 ? pa.z : pa.w;
                 static_for<0, 4>([&](auto R) { ntp[R.value] |= row == (uint32_t)R.value ? m : 0u; });
             }
