@@ -135,6 +135,24 @@ size_t marl_gae_workspace_bytes(int T, int N);
  * global reward mean.  d_workspace as for marl_gae. */
 int marl_row_sums(const float *d_x, int T, int N, double *d_sums, void *d_workspace, void *stream);
 
+/*
+ * Reward-event bookkeeping of the rollout driver, agent_environment.py:66-76: a step counts as a
+ * delivery when any reward is >= 1, as a plating when any is == 0.3, as an onion-in-pot when any
+ * is == 0.1 (float32 comparisons), and the episode return adds the mean reward.  The reference
+ * looks at rows 0..1 only; this call keeps that (d_first_rows) and adds the same for every env.
+ * Each call ADDS one step's rewards (float32 [num_envs * num_agents], env-major) to running
+ * totals the caller zeroes at the start of an episode:
+ *   d_totals      uint64[4]: sum over all rows of round(10 * reward) (exact: rewards are sums of
+ *                 0.1, 0.3 and whole numbers), number of envs with a delivery / a plating / an
+ *                 onion-in-pot this step.  Integer, so independent of summation order.
+ *   d_first_rows  double[4] or NULL: float32 mean of rewards[0:2] (added as a double, like the
+ *                 reference's Python float) and 0/1 flags for the three events among rows 0..1.
+ *   d_workspace   marl_reward_events_workspace_bytes() bytes, 8-byte aligned.
+ */
+int marl_reward_events(const float *d_rewards, int num_envs, int num_agents, uint64_t *d_totals,
+                       double *d_first_rows, void *d_workspace, void *stream);
+size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,9 @@ hipError_t launch_gae(const float* rewards, const float* dones, const float* val
 hipError_t launch_row_sums(const float* x, int T, int N, double* partial, double* sums, float* mean_out,
                            hipStream_t stream);
 int row_sum_chunks(int N);
+int reward_event_chunks(int N);
+hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
+                                double* first_rows, hipStream_t stream);
 }  // namespace oc
 
 using namespace oc;
@@ -505,4 +508,21 @@ extern "C" int marl_gae(const float* d_rewards, const float* d_dones, const floa
     hipError_t e = launch_gae(d_rewards, d_dones, d_values, d_next_values, T, N, (float)gamma, (float)(gamma * lam),
                               d_adv, d_ret, mode, mean, s);
     return e == hipSuccess ? MARL_OK : fail_hip(e, "gae kernel launch");
+}
+
+extern "C" size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents) {
+    if (num_envs <= 0 || num_agents <= 0) return 0;
+    return (size_t)reward_event_chunks(num_envs * num_agents) * 4 * sizeof(uint64_t);
+}
+
+extern "C" int marl_reward_events(const float* d_rewards, int num_envs, int num_agents, uint64_t* d_totals,
+                                  double* d_first_rows, void* d_workspace, void* stream) {
+    if (!d_rewards || !d_totals || !d_workspace) return fail(MARL_ERR_INVALID, "NULL argument to marl_reward_events");
+    if (num_envs <= 0 || num_agents <= 0 || (int64_t)num_envs * num_agents > 0x7FFFFFFF)
+        return fail(MARL_ERR_INVALID, "num_envs and num_agents must be positive and their product below 2^31");
+    if (((uintptr_t)d_workspace & 7u) != 0 || ((uintptr_t)d_totals & 7u) != 0 || ((uintptr_t)d_first_rows & 7u) != 0)
+        return fail(MARL_ERR_INVALID, "d_totals, d_first_rows and d_workspace must be 8-byte aligned");
+    hipError_t e = launch_reward_events(d_rewards, num_envs, num_agents, reinterpret_cast<uint64_t*>(d_workspace), d_totals,
+                                        d_first_rows, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "reward event kernel launch");
 }

@@ -1,0 +1,91 @@
+// Per-step reward-event bookkeeping of the rollout driver (agent_environment.py:66-76) as two
+// small launches instead of a dozen tensor ops, and for EVERY env instead of the first two rows.
+//
+// The reference classifies a step by comparing float32 rewards with constants: any reward >= 1
+// is a delivery, == 0.3 a plating, == 0.1 an onion put into a pot (rows 0..1 only, whatever the
+// agent count).  Kept literally for those rows; the all-env totals use the same comparisons per
+// env.  Rewards are sums of 0.1, 0.3 and whole numbers, so round(10 r) is exact and the totals
+// are integers: the result does not depend on the order of summation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oc {
+
+constexpr int EVENT_BLOCK = 256;
+
+int reward_event_chunks(int N) {
+    int c = (N + 2047) / 2048;
+    return c < 1 ? 1 : c > 256 ? 256 : c;
+}
+
+// pass 1: block c scans envs c, c + C, ... and writes its four sums to partial[c][4]
+__global__ void __launch_bounds__(EVENT_BLOCK)
+reward_events_partial_kernel(const float* __restrict__ rewards, int E, int A, uint64_t* __restrict__ partial) {
+    uint32_t tenths = 0, deliv = 0, plate = 0, pot = 0;  // per lane: at most E/blocks envs, far below 2^32
+    for (int e = blockIdx.x * EVENT_BLOCK + threadIdx.x; e < E; e += gridDim.x * EVENT_BLOCK) {
+        bool d = false, p = false, o = false;
+        for (int a = 0; a < A; ++a) {
+            const float r = rewards[(size_t)e * A + a];
+            tenths += (uint32_t)(r * 10.0f + 0.5f);
+            d |= r >= 1.0f;
+            p |= r == 0.3f;
+            o |= r == 0.1f;
+        }
+        deliv += d; plate += p; pot += o;
+    }
+    uint64_t v[4] = {tenths, deliv, plate, pot};
+    __shared__ uint64_t part[EVENT_BLOCK / 64][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t s = 0;
+        for (int w = 0; w < EVENT_BLOCK / 64; ++w) s += part[w][threadIdx.x];
+        partial[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+    }
+}
+
+// pass 2: lanes 0-3 add the chunk sums to the running totals; lane 4 does the first-rows part
+__global__ void reward_events_finish_kernel(const float* __restrict__ rewards, int N, const uint64_t* __restrict__ partial,
+                                            int C, uint64_t* __restrict__ totals, double* __restrict__ first_rows) {
+    const int k = threadIdx.x;
+    if (k < 4) {
+        uint64_t s = 0;
+        for (int c = 0; c < C; ++c) s += partial[(size_t)c * 4 + k];
+        totals[k] += s;
+    } else if (k == 4 && first_rows) {
+        // rewards[0:2].mean() in float32, then accumulated as a Python float (agent_environment.py:76)
+        const int n = N < 2 ? N : 2;
+        float sum = 0.0f;
+        bool d = false, p = false, o = false;
+        for (int j = 0; j < n; ++j) {
+            const float r = rewards[j];
+            sum = __fadd_rn(sum, r);
+            d |= r >= 1.0f; p |= r == 0.3f; o |= r == 0.1f;
+        }
+        first_rows[0] += (double)__fdiv_rn(sum, (float)n);
+        first_rows[1] += d ? 1.0 : 0.0;
+        first_rows[2] += p ? 1.0 : 0.0;
+        first_rows[3] += o ? 1.0 : 0.0;
+    }
+}
+
+hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
+                                double* first_rows, hipStream_t stream) {
+    const int C = reward_event_chunks(E * A);
+    hipLaunchKernelGGL(reward_events_partial_kernel, dim3(C), dim3(EVENT_BLOCK), 0, stream, rewards, E, A, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reward_events_finish_kernel, dim3(1), dim3(64), 0, stream, rewards, E * A, partial, C, totals,
+                       first_rows);
+    return hipGetLastError();
+}
+
+}  // namespace oc

@@ -8,10 +8,11 @@ update every ``num_steps`` -- with the per-step host round trips removed:
     agent_environment.py:50,63,106-107);
   * the env kernel writes the next observation straight into the rollout store's next row;
   * episode statistics accumulate on the device and are read back once per episode.
-Episode statistics keep the reference's definition (agent_environment.py:66-76,86-104: the
-first env's agents only; a delivery is any reward >= 1, a plating == 0.3, an onion-in-pot
-== 0.1; the return is the sum over steps of the mean reward of those agents) and add the
-same quantities averaged over every env of every rank.
+Episode statistics keep the reference's definition (agent_environment.py:66-76,86-104: rows
+0..1 only, whatever the agent count; a delivery is any reward >= 1, a plating == 0.3, an
+onion-in-pot == 0.1; the return is the sum over steps of the mean reward of those rows) and add
+the same quantities averaged over every env of every rank; both come from one small kernel
+pass per step (`episode_stats.EpisodeStats`).
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import torch
 
 from . import dist_utils
 from .env import OBS_KEY
+from .episode_stats import EpisodeStats
 
 
 class ScalarLog:
@@ -61,8 +63,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     episodes_reward, deliveries, platings, pottings = [], [], [], []
     all_env = {"episode_return_all_envs": [], "deliveries_all_envs": [], "platings_all_envs": [],
                "pottings_all_envs": []}
-    # [return(env0), delivery, plated, potted, return(all), delivery(all), plated(all), potted(all)]
-    acc = torch.zeros(8, dtype=torch.float64, device=device)
+    stats = EpisodeStats(E, A, device)
     steps_in_episode = 0
     num_episodes = 0
     global_step = 0
@@ -72,8 +73,6 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     env.reset(out=obs)
     dones = torch.zeros(N, dtype=torch.float32, device=device)
     carry = torch.empty_like(obs)  # holds the observation that follows the last stored row
-    thirty = torch.tensor(0.3, dtype=torch.float32, device=device)
-    tenth = torch.tensor(0.1, dtype=torch.float32, device=device)
 
     rng = range(num_update)
     if progress:
@@ -89,12 +88,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             nxt = buf.obs_slot(step + 1) if step + 1 < collect_steps else carry
             _, rewards, terminated, truncated, _ = env.step(actions, out=nxt)
 
-            r0 = rewards[0:A]
-            rall = rewards.view(E, A)
-            acc += torch.stack([
-                r0.mean(), (r0 >= 1).any().float(), (r0 == thirty).any().float(), (r0 == tenth).any().float(),
-                rall.mean(), (rall >= 1).any(1).float().mean(), (rall == thirty).any(1).float().mean(),
-                (rall == tenth).any(1).float().mean()]).double()
+            stats.add(rewards)
 
             agent.add_to_buffer(obs, actions, rewards, dones, logprobs, values.squeeze(1))
             steps_in_episode += 1
@@ -102,11 +96,13 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 # every env was stepped in lockstep and has just truncated; like the reference,
                 # restart all of them once more from the driver (agent_environment.py:86-88)
                 env.reset(out=nxt)
-                tot = acc.clone()
+                totals, first_rows = stats.raw()
+                tot_all = totals.to(torch.float64)
                 if dist_utils.world_size() > 1:
-                    dist_utils.all_reduce_sum_(tot[4:])
-                    tot[4:] /= dist_utils.world_size()
-                vals = tot.tolist()  # the one host sync per episode
+                    dist_utils.all_reduce_sum_(tot_all)
+                    tot_all /= dist_utils.world_size()
+                t = tot_all.tolist()  # the one host sync per episode
+                vals = first_rows.tolist() + [t[0] / 10.0 / N, t[1] / E, t[2] / E, t[3] / E]
                 episodes_reward.append(vals[0]); deliveries.append(vals[1]); platings.append(vals[2]); pottings.append(vals[3])
                 for k, v in zip(all_env, vals[4:]):
                     all_env[k].append(v)
@@ -117,7 +113,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                     writer.add_scalar("freq/frequency_ingredient_in_pot_per_episode", vals[3], num_episodes)
                     writer.add_scalar("all_envs/episode_return", vals[4], num_episodes)
                     writer.add_scalar("all_envs/deliveries_per_episode", vals[5], num_episodes)
-                acc.zero_()
+                stats.reset()
                 steps_in_episode = 0
                 num_episodes += 1
             obs = nxt

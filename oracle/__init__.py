@@ -166,3 +166,26 @@ def gae(rewards, dones, values, next_values, gamma=0.99, lam=0.95, mode=0):
 
 def rng_u32(seed, env_index, counter):
     return int(lib().oc_rng_u32(seed, env_index, counter))
+
+
+def reward_events(rewards, num_envs, num_agents):
+    """One step of the driver's reward bookkeeping (agent_environment.py:66-76), numpy.
+    Returns (totals int64[4], first_rows float64[4]):
+      totals     = [sum round(10 r), envs with any r >= 1, any r == 0.3, any r == 0.1] over all envs;
+      first_rows = [float32 mean of rewards[0:2], any >= 1, any == 0.3, any == 0.1] over rows 0..1,
+    with the comparisons made in float32 as torch does for a float32 tensor against a scalar."""
+    r = np.ascontiguousarray(rewards, dtype=np.float32).reshape(num_envs, num_agents)
+    totals = np.array([
+        int(np.floor(r.astype(np.float32) * np.float32(10.0) + np.float32(0.5)).astype(np.int64).sum()),
+        int((r >= np.float32(1.0)).any(axis=1).sum()),
+        int((r == np.float32(0.3)).any(axis=1).sum()),
+        int((r == np.float32(0.1)).any(axis=1).sum()),
+    ], dtype=np.int64)
+    head = r.reshape(-1)[0:2]
+    first = np.array([
+        float(head.mean(dtype=np.float32)),
+        float((head >= np.float32(1.0)).any()),
+        float((head == np.float32(0.3)).any()),
+        float((head == np.float32(0.1)).any()),
+    ], dtype=np.float64)
+    return totals, first

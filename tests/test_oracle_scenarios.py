@@ -271,3 +271,16 @@ def test_distance_metric_changes_only_the_order(oracle_mod, metric):
     counters = o[63:71].reshape(4, 2)
     d = np.abs(counters).sum(1) if metric == 0 else (counters ** 2).sum(1)
     assert (np.diff(d) >= 0).all()
+
+
+def test_reward_event_bookkeeping_by_hand(oracle_mod):
+    """agent_environment.py:66-76 on a hand-made step: env 0 pots an onion and plates, env 1
+    delivers (both agents get 1.0, one of them 1.1), env 2 idles."""
+    r = np.array([0.1, 0.3, 1.0, np.float32(0.1 + 1.0), 0.0, 0.0], dtype=np.float32)
+    totals, first = oracle_mod.reward_events(r, 3, 2)
+    assert totals.tolist() == [1 + 3 + 10 + 11, 1, 1, 1]
+    assert first.tolist() == [float(np.float32(0.1) + np.float32(0.3)) / 2, 0.0, 1.0, 1.0]
+    # four agents: the reference still looks at rows 0..1 only
+    r4 = np.array([0.0, 0.0, 1.0, 1.0], dtype=np.float32)
+    totals, first = oracle_mod.reward_events(r4, 1, 4)
+    assert totals.tolist() == [20, 1, 0, 0] and first.tolist() == [0.0, 0.0, 0.0, 0.0]
