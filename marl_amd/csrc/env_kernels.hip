@@ -43,6 +43,10 @@
 constexpr int STORE_NT = 2, STORE_SC1 = 16;
 
 namespace oc {
+// State, rewards and done flags are stored write-through as well (a relaxed system-scope atomic
+// store compiles to a plain store with the sc0 sc1 bits): nothing of a launch is left dirty in
+// the XCD L2s for the end-of-kernel write-back (18.92 -> 18.74 us on the headline config).
+template <class T> __device__ __forceinline__ void wt_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // ---------------------------------------------------------------------------------------
 // small helpers
@@ -192,16 +196,16 @@ template <int A, int NIW>
 __device__ __forceinline__ void store_state(const EnvState<A, NIW>& s, uint32_t* __restrict__ st, int E, int e) {
     uint32_t* p = st + e;
     const size_t stride = (size_t)E;
-    p[0] = s.t;
-    p[stride] = s.rng.ctr;
-    p[2 * stride] = s.pots;
+    wt_store(p, s.t);
+    wt_store(p + stride, s.rng.ctr);
+    wt_store(p + 2 * stride, s.pots);
     static_for<0, (A + 1) / 2>([&](auto K) {
         constexpr int k = K.value;
         uint32_t aw = s.f[2 * k] | (s.dir[2 * k] << 8) | (s.inv[2 * k] << 10);
         if constexpr (2 * k + 1 < A) aw |= (s.f[2 * k + 1] << 16) | (s.dir[2 * k + 1] << 24) | (s.inv[2 * k + 1] << 26);
-        p[(size_t)(3 + k) * stride] = aw;
+        wt_store(p + (size_t)(3 + k) * stride, aw);
     });
-    static_for<0, NIW>([&](auto K) { p[(size_t)(3 + (A + 1) / 2 + K.value) * stride] = s.items[K.value]; });
+    static_for<0, NIW>([&](auto K) { wt_store(p + (size_t)(3 + (A + 1) / 2 + K.value) * stride, s.items[K.value]); });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -691,9 +695,9 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             r += ((dish_mask >> i) & 1u) ? 0.3 : 0.0;
             static_for<0, A>([&](auto K) { r += ((deliver_mask >> K.value) & 1u) ? 1.0 : 0.0; });
             const bool trunc = s.t >= (uint32_t)P.max_steps;
-            rewards[row] = (float)r;
-            terminated[row] = 0;
-            truncated[row] = trunc ? 1 : 0;
+            wt_store(rewards + row, (float)r);
+            wt_store(terminated + row, (uint8_t)0);
+            wt_store(truncated + row, (uint8_t)(trunc ? 1 : 0));
             // vector-env semantics: a finished env restarts at once and reports the first
             // observation of the new episode together with the done flags
             if (trunc && P.auto_reset) reset_env<A, NIW>(s, T, P, nullptr, nullptr, aux_g, e);
