@@ -190,11 +190,26 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
     P.off_spawnf = off; off = align16(off + (int)spawn.size() + 1);
     P.off_inttab = off; off = align16(off + INT_TABLE_BYTES);
     P.off_rewtab = off; off = align16(off + REW_TABLE_BYTES);
+    P.off_rewval = off; off = align16(off + REW_VALUE_BYTES);
     P.tab_bytes = off;
     env->tab.assign((size_t)off, 0);
     uint8_t* t = env->tab.data();
 
     build_decision_tables(t + P.off_inttab, t + P.off_rewtab);
+    {
+        // rewards accumulate as Python floats in the config's list order
+        // [onion_in_pot 0.1, soup_in_dish 0.3, delivery 1.0 shared] (overcooked_config.py:96),
+        // then become float32 (agent_environment.py:63)
+        float* rv = reinterpret_cast<float*>(t + P.off_rewval);
+        for (int k = 0; k <= MAX_AGENTS; ++k)
+            for (int own = 0; own < 4; ++own) {
+                double r = 0.0;
+                r += (own & 1) ? 0.1 : 0.0;
+                r += (own & 2) ? 0.3 : 0.0;
+                for (int j = 0; j < k; ++j) r += 1.0;
+                rv[k * 4 + own] = (float)r;
+            }
+    }
     uint32_t* nb = reinterpret_cast<uint32_t*>(t + P.off_nb);
     uint16_t* frc = reinterpret_cast<uint16_t*>(t + P.off_frc);
     uint16_t* slotrc = reinterpret_cast<uint16_t*>(t + P.off_slotrc);

@@ -141,6 +141,7 @@ struct Lds {
     const EnvParams& P;
     __device__ __forceinline__ uint32_t int_entry(uint32_t idx) const { return b[P.off_inttab + idx]; }
     __device__ __forceinline__ uint32_t rew_entry(uint32_t idx) const { return b[P.off_rewtab + idx]; }
+    __device__ __forceinline__ float rew_value(uint32_t idx) const { return reinterpret_cast<const float*>(b + P.off_rewval)[idx]; }
     __device__ __forceinline__ uint4 nb(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_nb)[f]; }
     __device__ __forceinline__ uint4 pot_adj(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_adj)[2 * f]; }
     __device__ __forceinline__ uint4 adj_info(uint32_t f) const { return reinterpret_cast<const uint4*>(b + P.off_adj)[2 * f + 1]; }
@@ -665,6 +666,13 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
                                      : (uint32_t) reinterpret_cast<const uint8_t*>(actions)[r];
     });
 
+    // the env's RNG key needs nothing from memory: computed while the loads are in flight
+    uint32_t rng_key;
+    {
+        const uint64_t g = (((uint64_t)P.env_base_hi << 32) | P.env_base_lo) + (uint64_t)e;
+        const uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
+        rng_key = mix32(k ^ (uint32_t)(g >> 32));
+    }
     {
         const uint4* src = reinterpret_cast<const uint4*>(tab_g);
         uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -678,24 +686,18 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     if (active && !(ablate & 2)) {
         EnvState<A, NIW> s;
         unpack_state<A, NIW>(s, raw);
-        {
-            const uint64_t g = (((uint64_t)P.env_base_hi << 32) | P.env_base_lo) + (uint64_t)e;
-            const uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
-            s.rng.key = mix32(k ^ (uint32_t)(g >> 32));
-        }
+        s.rng.key = rng_key;
         OC_STAMP(2);
         if (mode == 0) {
             uint32_t onion_mask, dish_mask, deliver_mask;
             step_env<A, NIW>(s, T, P, act, prio, e, onion_mask, dish_mask, deliver_mask);
             OC_STAMP(3);
-            // rewards accumulate as Python floats in the config's list order
-            // [onion_in_pot 0.1, soup_in_dish 0.3, delivery 1.0 shared] (overcooked_config.py:96)
-            double r = 0.0;
-            r += ((onion_mask >> i) & 1u) ? 0.1 : 0.0;
-            r += ((dish_mask >> i) & 1u) ? 0.3 : 0.0;
-            static_for<0, A>([&](auto K) { r += ((deliver_mask >> K.value) & 1u) ? 1.0 : 0.0; });
+            // the reward is a function of (own events, deliveries in the env): the host summed it
+            // as Python floats in the config's list order and rounded once (csrc/capi.hip)
+            const float r = T.rew_value(((onion_mask >> i) & 1u) | (((dish_mask >> i) & 1u) << 1) |
+                                        ((uint32_t)__builtin_popcount(deliver_mask) << 2));
             const bool trunc = s.t >= (uint32_t)P.max_steps;
-            wt_store(rewards + row, (float)r);
+            wt_store(rewards + row, r);
             wt_store(terminated + row, (uint8_t)0);
             wt_store(truncated + row, (uint8_t)(trunc ? 1 : 0));
             // vector-env semantics: a finished env restarts at once and reports the first

@@ -96,6 +96,9 @@ enum : uint32_t { INT_ITEM_KEEP = 0, INT_ITEM_CLEAR = 1, INT_ITEM_PUT = 2 };
 enum : uint32_t { INT_POT_KEEP = 0, INT_POT_ADD = 1, INT_POT_RESET = 2 };
 constexpr int INT_TABLE_BYTES = 1024;
 constexpr int REW_TABLE_BYTES = 128;
+// reward values, float32[(MAX_AGENTS + 1) * 4], index = onion_in_pot | soup_in_dish << 1 | deliveries in the env << 2:
+// the Python-float sum 0.1 + 0.3 + 1.0 + ... in the config's list order, rounded to float32 once
+constexpr int REW_VALUE_BYTES = (4 + 1) * 4 * 4;
 
 // ---- hot lookup blob, indexed by FLOOR INDEX (agents only ever stand on floor cells) ----
 // All offsets are multiples of 16 bytes and live in EnvParams.
@@ -109,6 +112,7 @@ constexpr int REW_TABLE_BYTES = 128;
 //   potorder uint8[nfloor][2]      the two nearest pots (0xFF = none)
 //   spawnf   uint8[nspawn]         floor indices of the '+' cells
 //   inttab   uint8[1024], rewtab uint8[128]   the decision tables above
+//   rewval   float[20]             reward of an agent-step by (own events, deliveries in the env)
 struct EnvParams {
     int E;            // envs in this shard
     int NP;           // pots
@@ -120,7 +124,7 @@ struct EnvParams {
     int dist_metric;  // 0 = L1, 1 = squared L2
     int auto_reset;   // 1: a truncated env restarts inside the step (vector-env semantics)
     int stream_nt;    // 1: observation rows exceed the last-level cache, store them non-temporally
-    int off_nb, off_postab, off_adj, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab;
+    int off_nb, off_postab, off_adj, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab, off_rewval;
     uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard
 };
