@@ -620,6 +620,39 @@ __device__ __forceinline__ void write_block(uint8_t* img, uint32_t dst, const ui
     }
 }
 
+// Two agents, global_obs: a row is [own block | partner's block].  The lane takes the partner's
+// block from the neighbouring lane with 26 cross-lane moves, appends it to its own with
+// constant funnel shifts (BLK % 4 == 1), and stores its whole row once: even lanes' rows start
+// dword-aligned, odd lanes' rows two bytes later, so one funnel by 0 or 16 bits serves both and
+// the two bytes the dwords leave over (the row's last two or first two) go out as one
+// halfword.  Versus copying the block into both rows of the env this trades a few more VALU
+// instructions for 27 instead of 68 LDS stores per lane (18.68 -> 18.55 us per launch).
+template <int BLK, int NW>
+__device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, const uint32_t (&w)[NW]) {
+    static_assert(BLK % 4 == 1 && NW == BLK / 4 + 1, "block must end one byte into its last dword");
+    constexpr int KB = BLK / 4;            // whole dwords in a block
+    constexpr int NR = (2 * BLK + 3) / 4;  // dwords of a row, the last one half used
+    uint32_t p[NW];
+    static_for<0, NW>([&](auto K) {
+        // quad_perm [1, 0, 3, 2]: swap with the other lane of the pair
+        p[K.value] = (uint32_t)__builtin_amdgcn_mov_dpp((int)w[K.value], 0xB1, 0xF, 0xF, true);
+    });
+    uint32_t R[NR];
+    static_for<0, KB>([&](auto K) { R[K.value] = w[K.value]; });
+    R[KB] = (w[KB] & 0xFFu) | (p[0] << 8);
+    static_for<1, NW>([&](auto K) { R[KB + K.value] = __builtin_amdgcn_alignbit(p[K.value], p[K.value - 1], 24); });
+    const uint32_t odd = lane & 1u;
+    const uint32_t rot = odd * 16u;
+    uint8_t* row = img + lane * (uint32_t)(2 * BLK);
+    uint32_t* base = reinterpret_cast<uint32_t*>(row + odd * 2u);
+    static_for<0, NR - 1>([&](auto M) {
+        constexpr int m = M.value;
+        base[m] = __builtin_amdgcn_alignbit(R[m + 1], R[m], rot);
+    });
+    uint16_t* half = reinterpret_cast<uint16_t*>(row + (odd ? 0u : (uint32_t)(4 * (NR - 1))));
+    *half = (uint16_t)(odd ? R[0] : R[NR - 1]);
+}
+
 // ---------------------------------------------------------------------------------------
 // the kernel.  mode: 0 = step (+ auto-reset on truncation), 1 = reset every env,
 // 2 = featurize the stored state only.  Bits 8+ of mode are a profiling aid.
@@ -713,7 +746,9 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         Block<NW> blk;
         build_block<A, FEAT, NIW>(blk, s, T, P, i);
         OC_STAMP(5);
-        if constexpr (FEAT == FEAT_GLOBAL) {
+        if constexpr (FEAT == FEAT_GLOBAL && A == 2) {
+            write_row_pair<BLK, NW>(img, (uint32_t)lane, blk.w);
+        } else if constexpr (FEAT == FEAT_GLOBAL) {
             // my block goes into every row of my env: first in my own, after the lower ids elsewhere
             const uint32_t env_lane0 = (uint32_t)lane - i;
             static_for<0, A>([&](auto J) {
