@@ -132,6 +132,9 @@ static int build_tables(marl_env* env, const char* const* rows, int height, int 
     const int W = (int)strlen(rows[0]);
     if (W < 3 || H < 3) return fail(MARL_ERR_LAYOUT, "layout smaller than 3x3");
     if (H * W > MAX_CELLS) return fail(MARL_ERR_LAYOUT, "layout has more than 256 cells");
+    // the kernel orders "closest" candidates by 9-bit distance keys
+    if (dist_of(dist_metric, H - 1, W - 1) > 510)
+        return fail(MARL_ERR_LAYOUT, "layout too elongated for the squared-distance ordering (distance must stay below 511)");
     const int ncell = H * W;
     std::vector<uint8_t> type(ncell, WALL);
     std::vector<int> spawn, floor_cells, pot_cells, slots;

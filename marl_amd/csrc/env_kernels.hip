@@ -439,10 +439,15 @@ struct Block {
     }
 };
 
-// sorted (ascending) top-4 of 32-bit keys
+// sorted (ascending) top-4 of 32-bit keys.
+// Keys are (distance << 23) | (slot << 16) | (dx & 0xFF) << 8 | (dy & 0xFF): ordered by distance,
+// then by slot (= row-major cell order); the low 16 bits are the two feature bytes themselves.
+// An empty place holds TOP4_NONE: above every real key (distances stay below 2^9 - 1, so a real
+// key is below 0xFF800000) and with a zero payload, so emitting needs no "is it real" test.
+constexpr uint32_t TOP4_NONE = 0xFFFF0000u;
 struct Top4 {
     uint32_t k0, k1, k2, k3;
-    __device__ __forceinline__ void init() { k0 = k1 = k2 = k3 = 0xFFFFFFFFu; }
+    __device__ __forceinline__ void init() { k0 = k1 = k2 = k3 = TOP4_NONE; }
     __device__ __forceinline__ void insert(uint32_t x) {
         uint32_t lo;
         lo = min(k0, x); x = max(k0, x); k0 = lo;
@@ -452,14 +457,10 @@ struct Top4 {
     }
 };
 
-// Keys are (distance << 23) | (slot << 16) | (dx & 0xFF) << 8 | (dy & 0xFF): ordered by distance,
-// then by slot (= row-major cell order); the low 16 bits are the two feature bytes themselves.
-__device__ __forceinline__ uint32_t key_pair(uint32_t key) { return key != 0xFFFFFFFFu ? (key & 0xFFFFu) : 0u; }
-
 template <int OFF, int NW>
 __device__ __forceinline__ void emit_top4(Block<NW>& blk, const Top4& t) {
-    blk.template put4<OFF>(key_pair(t.k0) | (key_pair(t.k1) << 16));
-    blk.template put4<OFF + 4>(key_pair(t.k2) | (key_pair(t.k3) << 16));
+    blk.template put4<OFF>((t.k0 & 0xFFFFu) | (t.k1 << 16));
+    blk.template put4<OFF + 4>((t.k2 & 0xFFFFu) | (t.k3 << 16));
 }
 
 template <int OFF, int NW>
@@ -571,9 +572,9 @@ __device__ __forceinline__ void build_block(Block<FeatGeom<A, FEAT>::NW>& blk, c
                     const int dy = ar - (int)(orc >> 8), dx = ac - (int)(orc & 0xFFu);
                     const uint32_t d = P.dist_metric ? (uint32_t)(dy * dy + dx * dx) : (uint32_t)(abs(dy) + abs(dx));
                     const uint32_t key = (d << 23) | (slot << 16) | (((uint32_t)dx & 0xFFu) << 8) | ((uint32_t)dy & 0xFFu);
-                    onion.insert(kind == ONION ? key : 0xFFFFFFFFu);
-                    plate.insert(kind == PLATE ? key : 0xFFFFFFFFu);
-                    soup.insert(kind == SOUP ? key : 0xFFFFFFFFu);
+                    onion.insert(kind == ONION ? key : TOP4_NONE);
+                    plate.insert(kind == PLATE ? key : TOP4_NONE);
+                    soup.insert(kind == SOUP ? key : TOP4_NONE);
                 }
             });
             emit_top4<G::O_ONION>(blk, onion);
