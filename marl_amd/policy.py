@@ -50,11 +50,13 @@ class Agent(nn.Module):
 
     def get_action_and_value(self, x, action=None, joint_obs=None):
         hidden = self.network(x)
-        dist = Categorical(logits=self.actor(hidden))
+        # validate_args=False: the argument check reads a device flag back on the host, one
+        # synchronisation per call, and cannot run under hipGraph capture; it changes no result
+        dist = Categorical(logits=self.actor(hidden), validate_args=False)
         if action is None:
             action = dist.sample()
         value = self.centralised_critics(joint_obs) if joint_obs is not None else self.critic(hidden)
         return action, dist.log_prob(action), dist.entropy(), value
 
     def get_prob(self, x):
-        return Categorical(logits=self.actor(self.network(x)))
+        return Categorical(logits=self.actor(self.network(x)), validate_args=False)

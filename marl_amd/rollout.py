@@ -7,7 +7,10 @@ update every ``num_steps`` -- with the per-step host round trips removed:
     host-to-device copies, one device-to-host copy and a Python loop over rows per step,
     agent_environment.py:50,63,106-107);
   * the env kernel writes the next observation straight into the rollout store's next row;
-  * episode statistics accumulate on the device and are read back once per episode.
+  * episode statistics accumulate on the device and are read back once per episode;
+  * when a rollout is launch-bound (few rows per launch) its steps are captured once into
+    hipGraphs and replayed: one graph per (first row, length) segment, since the driver's
+    restart at the end of an episode cuts a rollout in two.
 Episode statistics keep the reference's definition (agent_environment.py:66-76,86-104: rows
 0..1 only, whatever the agent count; a delivery is any reward >= 1, a plating == 0.3, an
 onion-in-pot == 0.1; the return is the sum over steps of the mean reward of those rows) and add
@@ -59,6 +62,9 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     if log and writer is None:
         writer = make_writer(log_dir)
     max_steps = getattr(env, "max_steps", 1000)
+    # "auto": replay the rollout from hipGraphs when it is launch-bound (few rows per launch)
+    graph_mode = getattr(args, "graph_rollout", "off")
+    use_graphs = graph_mode == "on" or (graph_mode == "auto" and N <= 16384)
 
     episodes_reward, deliveries, platings, pottings = [], [], [], []
     all_env = {"episode_return_all_envs": [], "deliveries_all_envs": [], "platings_all_envs": [],
@@ -66,13 +72,49 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     stats = EpisodeStats(E, A, device)
     steps_in_episode = 0
     num_episodes = 0
-    global_step = 0
 
     buf = agent.buffer
-    obs = buf.obs_slot(0)
-    env.reset(out=obs)
-    dones = torch.zeros(N, dtype=torch.float32, device=device)
-    carry = torch.empty_like(obs)  # holds the observation that follows the last stored row
+    env.reset(out=buf.obs_slot(0))
+    dones = torch.zeros(N, dtype=torch.float32, device=device)  # flag produced by the step BEFORE the stored row
+    carry = torch.empty_like(buf.obs_slot(0))  # holds the observation that follows the last stored row
+
+    def slot(step):
+        return buf.obs_slot(step) if step < collect_steps else carry
+
+    def one_step(step):
+        # every tensor touched here has a fixed address per step index, so the same code can be
+        # captured into a graph and replayed
+        obs = slot(step)
+        actions, logprobs, _, values = agent.act(obs)
+        _, rewards, terminated, truncated, _ = env.step(actions, out=slot(step + 1))
+        stats.add(rewards)
+        agent.add_to_buffer(obs, actions, rewards, dones, logprobs, values.squeeze(1))
+        dones.copy_(terminated | truncated)
+
+    graphs = {}
+    pool = None
+
+    def run_segment(first, count, warm):
+        """steps [first, first + count) of the current rollout"""
+        nonlocal pool
+        if not (use_graphs and warm):
+            for step in range(first, first + count):
+                one_step(step)
+            return
+        g = graphs.get((first, count))
+        if g is None:
+            # capture records the launches without running them; the replay below does the work
+            buf.ptr = first
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                for step in range(first, first + count):
+                    one_step(step)
+            if pool is None:
+                pool = g.pool()
+            graphs[(first, count)] = g
+        g.replay()
+        buf.ptr = (first + count) % buf.max_size
+        buf.size = min(first + count, buf.max_size)
 
     rng = range(num_update)
     if progress:
@@ -82,20 +124,17 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             rng = tqdm(rng)
         except Exception:
             pass
-    for _ in rng:
-        for step in range(collect_steps):
-            actions, logprobs, _, values = agent.act(obs)
-            nxt = buf.obs_slot(step + 1) if step + 1 < collect_steps else carry
-            _, rewards, terminated, truncated, _ = env.step(actions, out=nxt)
-
-            stats.add(rewards)
-
-            agent.add_to_buffer(obs, actions, rewards, dones, logprobs, values.squeeze(1))
-            steps_in_episode += 1
+    for update_index in rng:
+        step = 0
+        while step < collect_steps:
+            count = min(collect_steps - step, max_steps - steps_in_episode)
+            run_segment(step, count, warm=update_index > 0)  # the first rollout runs eagerly (lazy library set-up)
+            step += count
+            steps_in_episode += count
             if steps_in_episode >= max_steps:
                 # every env was stepped in lockstep and has just truncated; like the reference,
                 # restart all of them once more from the driver (agent_environment.py:86-88)
-                env.reset(out=nxt)
+                env.reset(out=slot(step))
                 totals, first_rows = stats.raw()
                 tot_all = totals.to(torch.float64)
                 if dist_utils.world_size() > 1:
@@ -116,13 +155,9 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 stats.reset()
                 steps_in_episode = 0
                 num_episodes += 1
-            obs = nxt
-            dones = (terminated | truncated).float()
-            global_step += 1
-        agent.update(obs)
+        agent.update(carry)
         # the stored rows restart at 0: the carried observation becomes row 0
-        buf.obs_slot(0).copy_(obs)
-        obs = buf.obs_slot(0)
+        buf.obs_slot(0).copy_(carry)
 
     freq = {
         "frequency_delivery_per_episode": deliveries,
