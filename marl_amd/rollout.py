@@ -64,7 +64,8 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     max_steps = getattr(env, "max_steps", 1000)
     # "auto": replay the rollout from hipGraphs when it is launch-bound (few rows per launch)
     graph_mode = getattr(args, "graph_rollout", "off")
-    use_graphs = graph_mode == "on" or (graph_mode == "auto" and N <= 16384)
+    # and the job is a single rank ("on" forces it; multi-rank replay is exercised over gloo only)
+    use_graphs = graph_mode == "on" or (graph_mode == "auto" and N <= 16384 and dist_utils.world_size() == 1)
 
     episodes_reward, deliveries, platings, pottings = [], [], [], []
     all_env = {"episode_return_all_envs": [], "deliveries_all_envs": [], "platings_all_envs": [],
@@ -106,7 +107,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             # capture records the launches without running them; the replay below does the work
             buf.ptr = first
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 for step in range(first, first + count):
                     one_step(step)
             if pool is None:
@@ -115,6 +116,13 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         g.replay()
         buf.ptr = (first + count) % buf.max_size
         buf.size = min(first + count, buf.max_size)
+
+    def drain_before_collective():
+        # A collective's stream waits on an event recorded behind the graph launch; with ranks
+        # sharing work through gloo that wait was seen never to return on ROCm 7.2 unless the
+        # launch stream had drained first.  Once per rollout / per episode: no measurable cost.
+        if use_graphs and dist_utils.world_size() > 1:
+            torch.cuda.current_stream(device).synchronize()
 
     rng = range(num_update)
     if progress:
@@ -137,6 +145,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 env.reset(out=slot(step))
                 totals, first_rows = stats.raw()
                 tot_all = totals.to(torch.float64)
+                drain_before_collective()
                 if dist_utils.world_size() > 1:
                     dist_utils.all_reduce_sum_(tot_all)
                     tot_all /= dist_utils.world_size()
@@ -155,6 +164,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 stats.reset()
                 steps_in_episode = 0
                 num_episodes += 1
+        drain_before_collective()
         agent.update(carry)
         # the stored rows restart at 0: the carried observation becomes row 0
         buf.obs_slot(0).copy_(carry)

@@ -58,7 +58,7 @@ def build_parser():
     p.add_argument("--max-steps", type=int, default=1000, help="episode length (overcooked_config.py:108)")
     p.add_argument("--shuffle", choices=["device", "numpy"], default="device")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
-                   help="replay rollout steps from hipGraphs (auto: when a launch covers at most 16,384 rows)")
+                   help="replay rollout steps from hipGraphs (auto: single rank and at most 16,384 rows per launch)")
     return p
 
 

@@ -43,7 +43,8 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
         f"torch.save(keep['p'], os.path.join({str(tmp_path)!r}, 'params%s.pt' % os.environ['RANK']))\n")
     r = _launch([str(script)], ["--num-agents", "2", "--num-envs", "8", "--layout", "overcooked_cramped_room_v0",
                                 "--num-steps", "16", "--total-steps", str(8 * 2 * 16 * 3), "--ppo-epoch", "2",
-                                "--max-steps", "20", "--data-path", str(tmp_path / "data"), "--algorithm", "cmappo"])
+                                "--max-steps", "20", "--data-path", str(tmp_path / "data"), "--algorithm", "cmappo",
+                                "--graph-rollout", "on"])
     assert r.returncode == 0, r.stderr[-3000:]
     p0 = torch.load(tmp_path / "params0.pt")
     p1 = torch.load(tmp_path / "params1.pt")
