@@ -47,7 +47,7 @@ const char *marl_last_error(void);
  * Build an env family on the current HIP device.
  * Stands behind main.py:29-64 `make_env` + main.py:66-96 `make_vector_env`:
  *   layout_rows/height  the ASCII grid (overcooked_config.py:34-62 legend; '+' = spawn floor)
- *   num_agents          1, 2 or 4 (config["num_agents"], main.py:48)
+ *   num_agents          1 to 4 (config["num_agents"], main.py:48)
  *   feature             MARL_FEAT_* (config["features"], main.py:50)
  *   max_steps           episode length before truncation (overcooked_config.py:108)
  *   num_envs            E, envs held by THIS process (rows = E * num_agents, env-major)

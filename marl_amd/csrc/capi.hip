@@ -26,6 +26,9 @@ extern template hipError_t launch_env_kernel_A<1>(int, int, const EnvParams&, co
 extern template hipError_t launch_env_kernel_A<2>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
                                                   const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
                                                   uint8_t*, int, hipStream_t);
+extern template hipError_t launch_env_kernel_A<3>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
+                                                  const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
+                                                  uint8_t*, int, hipStream_t);
 extern template hipError_t launch_env_kernel_A<4>(int, int, const EnvParams&, const uint8_t*, const uint8_t*, uint32_t*, const void*, int,
                                                   const uint8_t*, const uint8_t*, const uint8_t*, float*, float*, uint8_t*,
                                                   uint8_t*, int, hipStream_t);
@@ -356,8 +359,8 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
                                int dist_metric) {
     if (!out) return fail(MARL_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (num_agents != 1 && num_agents != 2 && num_agents != 4)
-        return fail(MARL_ERR_INVALID, "num_agents must be 1, 2 or 4 (one lane per agent row, 64 lanes per wave)");
+    if (num_agents < 1 || num_agents > MAX_AGENTS)
+        return fail(MARL_ERR_INVALID, "num_agents must be 1, 2, 3 or 4");
     if (feature < 0 || feature > FEAT_ONLY_DIRECTION) return fail(MARL_ERR_INVALID, "unknown feature id");
     if (max_steps <= 0 || max_steps > 65535) return fail(MARL_ERR_INVALID, "max_steps must be in [1, 65535]");
     if (num_envs <= 0) return fail(MARL_ERR_INVALID, "num_envs must be positive");
@@ -429,6 +432,7 @@ static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, i
     switch (env->A) {
         case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
         case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 3: e = launch_env_kernel_A<3>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
         case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
         default: return fail(MARL_ERR_INVALID, "unsupported agent count");
     }

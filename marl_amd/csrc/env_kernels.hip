@@ -671,14 +671,20 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     constexpr int NRAW = 3 + (A + 1) / 2 + NIW;
     extern __shared__ __align__(16) uint8_t smem[];
 
+    // A wave serves EPW whole envs; an env takes LPE lanes (A rounded up to a power of two, the
+    // spare lanes idle), so that the lanes of one env always share a wave.
+    constexpr int LPE = lanes_per_env(A), EPW = 64 / LPE, RPW = EPW * A;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const size_t N = (size_t)P.E * A;
-    const size_t row0 = ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64;  // first row of this wave
-    const size_t row = row0 + lane;
-    const bool active = row < N;
-    const int e = active ? (int)(row / A) : 0;
-    const uint32_t i = (uint32_t)(row % A);
+    const size_t wave_global = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const size_t row0 = wave_global * RPW;  // first row of this wave
+    const uint32_t i = (uint32_t)lane % LPE;
+    const uint32_t env_local = (uint32_t)lane / LPE;
+    const uint32_t row_local = env_local * A + i;  // row within the wave's image
+    const bool active = i < (uint32_t)A && wave_global * EPW + env_local < (size_t)P.E;
+    const int e = active ? (int)(wave_global * EPW + env_local) : 0;
+    const size_t row = row0 + row_local;
     const int ablate = mode >> 8;  // 1 = skip the store stream, 2 = skip the simulation (timing only)
     mode &= 0xFF;
 #ifdef OC_STAMPS
@@ -715,7 +721,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     __syncthreads();
     OC_STAMP(1);
     Lds T{smem, P};
-    uint8_t* img = smem + P.tab_bytes + wave * (64 * D);
+    uint8_t* img = smem + P.tab_bytes + wave * (RPW * D);
 
     if (active && !(ablate & 2)) {
         EnvState<A, NIW> s;
@@ -751,14 +757,14 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
             write_row_pair<BLK, NW>(img, (uint32_t)lane, blk.w);
         } else if constexpr (FEAT == FEAT_GLOBAL) {
             // my block goes into every row of my env: first in my own, after the lower ids elsewhere
-            const uint32_t env_lane0 = (uint32_t)lane - i;
+            const uint32_t env_row0 = env_local * A;
             static_for<0, A>([&](auto J) {
                 constexpr uint32_t j = J.value;
                 const uint32_t slot = (j == i) ? 0u : (i < j ? i + 1u : i);
-                write_block<BLK, NW>(img, (env_lane0 + j) * D + slot * BLK, blk.w);
+                write_block<BLK, NW>(img, (env_row0 + j) * D + slot * BLK, blk.w);
             });
         } else {
-            write_block<BLK, NW>(img, (uint32_t)lane * D, blk.w);
+            write_block<BLK, NW>(img, row_local * D, blk.w);
         }
     }
     OC_STAMP(6);
@@ -773,9 +779,10 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     // go through a wave-uniform buffer descriptor over exactly this wave's rows (the hardware
     // range check drops anything past the end).
     if (row0 < N && !(ablate & 1)) {
-        const size_t rows_here = (N - row0) < 64 ? (N - row0) : 64;
+        const size_t rows_here = (N - row0) < (size_t)RPW ? (N - row0) : (size_t)RPW;
         const uint32_t nfloat = (uint32_t)(rows_here * D);
-        const uint32_t nchunk = nfloat / 4;  // 64*D is a multiple of 4; the tail of a short last group is handled below
+        static_assert((RPW * D) % 4 == 0, "a full group of rows is a whole number of 16-byte chunks");
+        const uint32_t nchunk = nfloat / 4;  // the tail of a short last group is handled below
         const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
         // the descriptor must be provably wave-uniform (scalar registers), or every store is
         // wrapped in a lane-by-lane loop: the wave index comes from threadIdx, so say it explicitly
@@ -797,7 +804,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         // the 12-bit instruction offset but NOT the scalar offset operand, so a constant passed
         // there would let the tail lanes write past the group's rows.  The compiler splits the
         // sum into a multiple of 4096 (one add per four iterations) and the instruction offset.
-        constexpr int ITERS = (16 * D + 63) / 64;
+        constexpr int ITERS = (RPW * D / 4 + 63) / 64;
         const uint32_t* my = img32 + lane;
         const uint32_t voff = (uint32_t)lane * 16u;
         // Cache policy of the stores (measured on MI355X): below the size of the last-level
@@ -829,7 +836,7 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
 #ifdef OC_STAMPS
     OC_STAMP(7);
     if (stamp_out && lane == 0) {
-        uint64_t* o = stamp_out + (row0 / 64) * 10;
+        uint64_t* o = stamp_out + wave_global * 10;
         static_for<0, 8>([&](auto K) { o[K.value] = stamp[K.value]; });
         o[8] = wall_clock64();
         o[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
@@ -849,8 +856,9 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
     static const int waves_req = [] { const char* v = getenv("MARL_AMD_WAVES"); return v ? atoi(v) : 4; }();  // tuning aid
     int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4 || waves_req == 8) ? waves_req : 4;
-    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * 64 * G::D > (waves_req == 8 ? 128 : 64) * 1024) waves >>= 1;
-    const size_t lds = (size_t)P.tab_bytes + (size_t)waves * 64 * G::D;
+    constexpr int RPW = 64 / lanes_per_env(A) * A;  // rows per wave
+    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * RPW * G::D > (waves_req == 8 ? 128 : 64) * 1024) waves >>= 1;
+    const size_t lds = (size_t)P.tab_bytes + (size_t)waves * RPW * G::D;
     static size_t configured[64] = {0};  // per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -861,7 +869,7 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
         configured[dev] = lds;
     }
     const size_t N = (size_t)P.E * A;
-    const size_t rows_per_block = (size_t)waves * 64;
+    const size_t rows_per_block = (size_t)waves * RPW;
     const unsigned grid = (unsigned)((N + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((env_kernel<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
                        actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);

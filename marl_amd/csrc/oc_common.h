@@ -24,6 +24,8 @@ constexpr int MAX_CELLS = 256;
 constexpr int MAX_POTS = 4;     // one byte per pot in a single state word
 constexpr int MAX_SLOTS = 126;  // item-capable cells; 127 is the "no slot" code
 constexpr int MAX_AGENTS = 4;
+// lanes one env takes in a wave: the agent count rounded up to a power of two
+constexpr int lanes_per_env(int A) { return A <= 1 ? 1 : A <= 2 ? 2 : 4; }
 
 // pot condition classes and where each lands in the two pot encodings.
 // An empty pot is row 0 of NextToPot and index 1 of the pot-feature status one-hot: both

@@ -20,6 +20,10 @@ CASES = [
     ("overcooked_cramped_room_v0", 2, "Minimal_spatial_other_agent_aware", 70, 40, 100),
     ("overcooked_cramped_room_v0", 4, "only_direction", 33, 30, 80),
     ("overcooked_cramped_room_v0", 1, "global_obs", 50, 30, 80),
+    # three agents: four lanes per env, one idle; 48 rows per wave
+    ("overcooked_coordination_ring_v0", 3, "global_obs", 77, 40, 160),
+    ("overcooked_cramped_room_v0", 3, "local_obs", 130, 35, 120),
+    ("large_overcooked_layout", 3, "Minimal_spatial_other_agent_aware", 45, 60, 130),
 ]
 
 
