@@ -29,8 +29,8 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     L = _lib.lib()
     handle = ctypes.c_void_p()
     rows = (ctypes.c_char_p * 3)(b"###", b"# #", b"###")
-    # 3 agents are not supported by the lane mapping; rejected before any HIP call
-    rc = L.marl_env_create(ctypes.byref(handle), rows, 3, 3, 0, 1000, 4, 0, 0, 0)
+    # more than 4 agents are not supported by the lane mapping; rejected before any HIP call
+    rc = L.marl_env_create(ctypes.byref(handle), rows, 3, 5, 0, 1000, 4, 0, 0, 0)
     assert rc == -1 and b"num_agents" in L.marl_last_error()
     rc = L.marl_env_create(ctypes.byref(handle), rows, 3, 2, 9, 1000, 4, 0, 0, 0)
     assert rc == -1 and b"feature" in L.marl_last_error()
