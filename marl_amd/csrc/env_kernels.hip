@@ -21,7 +21,8 @@
 // others in agent-id order).
 #include <hip/hip_runtime.h>
 // Profiling aid: with -DOC_STAMPS the priority-override argument is taken as a uint64 buffer
-// [waves][10] that receives each wave's cycle counter after every phase (no override then).
+// [waves][16] that receives each wave's cycle counter after every phase, the 100 MHz wall clock at
+// start / simulation done / end, and where the wave ran (no override then).
 #ifdef OC_STAMPS
 #define OC_STAMP(k) stamp[k] = __builtin_readcyclecounter()
 #else
@@ -692,6 +693,8 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
     uint64_t* stamp_out = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(prio));
     prio = nullptr;
     OC_STAMP(0);
+    const uint64_t wall0 = wall_clock64();
+    uint64_t wall1 = 0;
 #endif
 
     // issue the HBM reads first so that they fly while the lookup blob is staged
@@ -768,6 +771,9 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
         }
     }
     OC_STAMP(6);
+#ifdef OC_STAMPS
+    wall1 = wall_clock64();
+#endif
     // A wave's row image is written and read by that wave alone (the A lanes of an env share a
     // wave), and LDS operations of one wave complete in order: ordering within the wave is
     // all that is needed, so waves of a workgroup start streaming as soon as they are done.
@@ -836,10 +842,13 @@ env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __rest
 #ifdef OC_STAMPS
     OC_STAMP(7);
     if (stamp_out && lane == 0) {
-        uint64_t* o = stamp_out + wave_global * 10;
+        uint64_t* o = stamp_out + wave_global * 16;
         static_for<0, 8>([&](auto K) { o[K.value] = stamp[K.value]; });
         o[8] = wall_clock64();
         o[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
+        o[10] = wall0;
+        o[11] = wall1;
+        o[12] = __builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_ID
     }
 #endif
 }

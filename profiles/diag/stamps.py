@@ -9,12 +9,12 @@ obs = torch.empty((N, D), device="cuda"); rew = torch.empty(N, device="cuda")
 term = torch.empty(N, dtype=torch.bool, device="cuda"); trunc = torch.empty_like(term)
 env.reset(out=obs)
 nw = N // 64
-dbg = torch.zeros(nw * 10, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
 acts = torch.randint(0, 7, (8, N), device="cuda")
 for i in range(50):
     env.step_into(acts[i % 8], obs, rew, term, trunc, prio_override=dbg)
 torch.cuda.synchronize()
-full = dbg.cpu().numpy().reshape(nw, 10)
+full = dbg.cpu().numpy().reshape(nw, 16)
 s = full[:, :8]
 t0 = s[:, 0].min()
 d = np.diff(s, axis=1)

@@ -33,3 +33,10 @@ h, _ = np.histogram(us(rt2), bins=np.arange(0, 30, 1.0))
 print("end-time histogram per us:", h.tolist())
 h, _ = np.histogram(us(rt0), bins=np.arange(0, 30, 1.0))
 print("start-time histogram per us:", h.tolist())
+# per-XCD view in wall-clock time
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("xcc %d: start p50 %.2f  sim-done p50 %.2f  end p50 %.2f p100 %.2f  stream p50 %.2f" % (
+            x, np.median(us(rt0[m])), np.median(us(rt1[m])), np.median(us(rt2[m])), us(rt2[m]).max(),
+            np.median((rt2[m] - rt1[m]) / 100.0)))
