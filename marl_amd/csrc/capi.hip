@@ -58,6 +58,7 @@ static int fail_hip(hipError_t e, const char* what) {
 struct marl_env {
     EnvParams P;
     int A, feat, niw, H, W, ncell, NP, D, BLK, words;
+    int device;                // HIP device that holds the tables; every call must run with it current
     std::vector<uint8_t> tab;  // host copy of the hot lookup blob
     std::vector<uint8_t> aux;  // host copy of the cell-indexed tables of the snapshot kernels
     uint8_t* d_tab;
@@ -382,7 +383,8 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     P.seed_key = mix32_host(k ^ (uint32_t)(seed >> 32));
     P.env_base_lo = (uint32_t)(uint64_t)env_index_base;
     P.env_base_hi = (uint32_t)((uint64_t)env_index_base >> 32);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&env->d_tab), env->tab.size());
+    hipError_t e = hipGetDevice(&env->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&env->d_tab), env->tab.size());
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&env->d_aux), env->aux.size());
     if (e == hipSuccess) e = hipMemcpy(env->d_tab, env->tab.data(), env->tab.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(env->d_aux, env->aux.data(), env->aux.size(), hipMemcpyHostToDevice);
@@ -428,6 +430,11 @@ static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, i
     if (((uintptr_t)d_state & 3u) != 0) return fail(MARL_ERR_INVALID, "d_state must be 4-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
+    int dev = -1;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return fail_hip(e, "hipGetDevice");
+    if (dev != env->device)
+        return fail(MARL_ERR_INVALID, "the env was created on HIP device " + std::to_string(env->device) +
+                                          " but device " + std::to_string(dev) + " is current");
     uint32_t* st = reinterpret_cast<uint32_t*>(d_state);
     switch (env->A) {
         case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
