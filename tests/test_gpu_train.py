@@ -118,3 +118,25 @@ def test_numpy_io_mode_runs_a_reference_shaped_loop():
             n_done += 1
         obs = torch.FloatTensor(next_obs[OBS_KEY]).to(dev)
     assert n_done == 2
+
+
+def test_rollout_forward_equals_training_forward():
+    """Without autograd the policy trunk runs as GEMMs with a fused bias + ReLU epilogue; the
+    outputs must be the same float32 numbers the plain nn.Sequential produces."""
+    from marl_amd.env import make_env, make_vector_env
+    from marl_amd.policy import Agent
+
+    dev = torch.device("cuda:0")
+    env = make_env(2, "overcooked_cramped_room_v0", "global_obs")
+    vec = make_vector_env(64, env, device=dev)
+    torch.manual_seed(5)
+    net = Agent(vec.single_observation_space, vec.single_action_space, 2, 64).to(dev)
+    obs = vec.reset()[0]["n_agent_overcooked_features"]
+    for _ in range(3):
+        obs = vec.step(torch.randint(0, 7, (128,), device=dev))[0]["n_agent_overcooked_features"]
+    actions = torch.randint(0, 7, (128,), device=dev)
+    _, lp_g, ent_g, v_g = net.get_action_and_value(obs, actions)  # autograd on: nn.Sequential
+    with torch.no_grad():
+        _, lp_n, ent_n, v_n = net.get_action_and_value(obs, actions)  # fused epilogue
+        assert torch.equal(net.get_value(obs), v_n)
+    assert torch.equal(lp_g.detach(), lp_n) and torch.equal(ent_g.detach(), ent_n) and torch.equal(v_g.detach(), v_n)
