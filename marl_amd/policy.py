@@ -19,6 +19,51 @@ def _ortho(linear: nn.Linear, gain: float = math.sqrt(2.0), bias: float = 0.0) -
     return linear
 
 
+def _weight_grad(gy, x):
+    """gy^T @ x for a tall batch (K rows, K >> features).  hipBLASLt's kernel choice for this
+    skinny shape leaves most of the chip idle (1.15 ms for 512 x 202 over K = 262,144); cutting K
+    into S slabs, one batched GEMM and a sum over the slabs is 2-4x faster on MI355X
+    (0.50 ms for the same shape).  Same float32 products, another summation order."""
+    K = gy.shape[0]
+    S = 1
+    while S < 128 and K % (2 * S) == 0 and K // (2 * S) >= 2048:
+        S *= 2
+    if S == 1 or not gy.is_cuda:
+        return gy.t() @ x
+    return torch.bmm(gy.view(S, K // S, -1).transpose(1, 2), x.view(S, K // S, -1)).sum(0)
+
+
+class _LinearReLU(torch.autograd.Function):
+    """relu(x @ W^T + b) (or without the ReLU) as one GEMM with a fused epilogue; the backward
+    pass forms the weight gradient with `_weight_grad`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if relu:
+            out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        else:
+            out = torch.addmm(bias, x, weight.t())
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, out = ctx.saved_tensors
+        if ctx.relu:
+            gy = torch.ops.aten.threshold_backward(gy, out, 0)
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        return gx, _weight_grad(gy, x), gy.sum(0), None
+
+
+def _linear(layer: nn.Linear, x, relu):
+    if x.is_cuda and x.dim() == 2:
+        return _LinearReLU.apply(x.contiguous(), layer.weight, layer.bias, relu)
+    out = layer(x)
+    return torch.relu(out) if relu else out
+
+
 def _mlp(sizes, final_activation):
     layers = []
     for k in range(len(sizes) - 1):
@@ -41,14 +86,10 @@ class Agent(nn.Module):
         self.centralised_critics = _mlp([d * self.num_agents * self.num_envs, 512, 256, 1], final_activation=False)
 
     def _trunk(self, x):
-        """network(x).  Without autograd (rollouts) on the GPU each Linear + ReLU pair runs as one
-        hipBLASLt GEMM with the bias and the ReLU in its epilogue: the same float32 result bit for
-        bit, one pass less over the activations (250 us instead of 365 us for 131,072 x 202 -> 512)."""
-        if torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2:
-            return self.network(x)
-        l0, l2 = self.network[0], self.network[2]
-        h = torch._addmm_activation(l0.bias, x, l0.weight.t(), use_gelu=False)
-        return torch._addmm_activation(l2.bias, h, l2.weight.t(), use_gelu=False)
+        """network(x): each Linear + ReLU pair runs as one hipBLASLt GEMM with the bias and the
+        ReLU in its epilogue: the same float32 result bit for bit, one pass less over the
+        activations (250 us instead of 365 us for 131,072 x 202 -> 512)."""
+        return _linear(self.network[2], _linear(self.network[0], x, True), True)
 
     def get_value(self, x, joint_obs=None):
         if joint_obs is not None:
@@ -56,17 +97,17 @@ class Agent(nn.Module):
             if joint_obs.shape[1] != want:
                 raise ValueError(f"joint_obs has width {joint_obs.shape[1]}, expected {want}")
             return self.centralised_critics(joint_obs)
-        return self.critic(self._trunk(x))
+        return _linear(self.critic, self._trunk(x), False)
 
     def get_action_and_value(self, x, action=None, joint_obs=None):
         hidden = self._trunk(x)
         # validate_args=False: the argument check reads a device flag back on the host, one
         # synchronisation per call, and cannot run under hipGraph capture; it changes no result
-        dist = Categorical(logits=self.actor(hidden), validate_args=False)
+        dist = Categorical(logits=_linear(self.actor, hidden, False), validate_args=False)
         if action is None:
             action = dist.sample()
-        value = self.centralised_critics(joint_obs) if joint_obs is not None else self.critic(hidden)
+        value = self.centralised_critics(joint_obs) if joint_obs is not None else _linear(self.critic, hidden, False)
         return action, dist.log_prob(action), dist.entropy(), value
 
     def get_prob(self, x):
-        return Categorical(logits=self.actor(self._trunk(x)), validate_args=False)
+        return Categorical(logits=_linear(self.actor, self._trunk(x), False), validate_args=False)

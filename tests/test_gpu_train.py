@@ -120,23 +120,43 @@ def test_numpy_io_mode_runs_a_reference_shaped_loop():
     assert n_done == 2
 
 
-def test_rollout_forward_equals_training_forward():
-    """Without autograd the policy trunk runs as GEMMs with a fused bias + ReLU epilogue; the
-    outputs must be the same float32 numbers the plain nn.Sequential produces."""
+def test_policy_forward_and_gradients_match_plain_layers():
+    """The policy runs Linear(+ReLU) as GEMMs with a fused epilogue and forms weight gradients
+    from K-slabs.  Against the plain nn.Linear / nn.ReLU layers of the same parameters: forward
+    outputs are the same float32 numbers, gradients agree to summation-order noise."""
     from marl_amd.env import make_env, make_vector_env
     from marl_amd.policy import Agent
 
     dev = torch.device("cuda:0")
     env = make_env(2, "overcooked_cramped_room_v0", "global_obs")
-    vec = make_vector_env(64, env, device=dev)
+    E = 4096  # 8192 rows: large enough for the slab path
+    vec = make_vector_env(E, env, device=dev)
     torch.manual_seed(5)
-    net = Agent(vec.single_observation_space, vec.single_action_space, 2, 64).to(dev)
+    net = Agent(vec.single_observation_space, vec.single_action_space, 2, 1).to(dev)
     obs = vec.reset()[0]["n_agent_overcooked_features"]
     for _ in range(3):
-        obs = vec.step(torch.randint(0, 7, (128,), device=dev))[0]["n_agent_overcooked_features"]
-    actions = torch.randint(0, 7, (128,), device=dev)
-    _, lp_g, ent_g, v_g = net.get_action_and_value(obs, actions)  # autograd on: nn.Sequential
+        obs = vec.step(torch.randint(0, 7, (2 * E,), device=dev))[0]["n_agent_overcooked_features"]
+    actions = torch.randint(0, 7, (2 * E,), device=dev)
+
+    def plain(x):
+        h = net.network(x)
+        logits, value = net.actor(h), net.critic(h)
+        dist = torch.distributions.Categorical(logits=logits)
+        return dist.log_prob(actions), dist.entropy(), value
+
+    def loss_of(lp, ent, v):
+        return (lp * 0.7).mean() - 0.01 * ent.mean() + 0.5 * (v.squeeze(1) ** 2).mean()
+
+    lp_p, ent_p, v_p = plain(obs)
+    g_plain = torch.autograd.grad(loss_of(lp_p, ent_p, v_p), list(net.parameters()), allow_unused=True)
+    _, lp, ent, v = net.get_action_and_value(obs, actions)
+    assert torch.equal(lp, lp_p) and torch.equal(ent, ent_p) and torch.equal(v, v_p)
+    g_fast = torch.autograd.grad(loss_of(lp, ent, v), list(net.parameters()), allow_unused=True)
+    for (name, _), a, b in zip(net.named_parameters(), g_plain, g_fast):
+        if a is None:
+            assert b is None, name
+            continue
+        torch.testing.assert_close(b, a, rtol=2e-4, atol=1e-7 + 1e-5 * a.abs().max().item(), msg=name)
     with torch.no_grad():
-        _, lp_n, ent_n, v_n = net.get_action_and_value(obs, actions)  # fused epilogue
-        assert torch.equal(net.get_value(obs), v_n)
-    assert torch.equal(lp_g.detach(), lp_n) and torch.equal(ent_g.detach(), ent_n) and torch.equal(v_g.detach(), v_n)
+        _, lp_n, ent_n, v_n = net.get_action_and_value(obs, actions)
+        assert torch.equal(lp_n, lp_p) and torch.equal(v_n, v_p) and torch.equal(net.get_value(obs), v_p)
