@@ -71,6 +71,30 @@ def test_rollout_parity(oracle_mod, layout, A, feature, E, max_steps, steps):
         assert total_reward > 0, "rollout never earned a reward: the test is not exercising pots"
 
 
+@pytest.mark.parametrize("A", [1, 2, 3, 4])
+@pytest.mark.parametrize("E", [1, 17])
+def test_tiny_batches_and_constant_restarts(oracle_mod, A, E):
+    """One env (a single, mostly idle wave) and a ragged 17, with episodes of 3 steps so that
+    every third step restarts every env inside the kernel."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_coordination_ring_v0")
+    for feature in ("global_obs", "only_direction"):
+        gpu = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=3, seed=21, env_index_base=5)
+        ora = oracle_mod.OracleVecEnv(rows, A, feature, max_steps=3, num_envs=E, seed=21, env_index_base=5)
+        np.testing.assert_array_equal(gpu.reset()[0][OBS_KEY].cpu().numpy(), ora.reset())
+        rng = np.random.default_rng(E * 10 + A)
+        for t in range(31):
+            act = rng.integers(0, 7, size=E * A)
+            o_g, r_g, _, tr_g, _ = gpu.step(torch.from_numpy(act))
+            o_o, r_o, _, tr_o = ora.step(act)
+            np.testing.assert_array_equal(o_g[OBS_KEY].cpu().numpy(), o_o, err_msg=f"{feature} step {t}")
+            np.testing.assert_array_equal(r_g.cpu().numpy(), r_o)
+            np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o)
+            assert bool(tr_o.all()) == ((t + 1) % 3 == 0)
+        _assert_state_equal(gpu, ora)
+
+
 @pytest.mark.parametrize("act_dtype", [torch.int64, torch.int32, torch.uint8])
 def test_action_dtypes_and_priority_override(oracle_mod, act_dtype):
     from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
