@@ -138,7 +138,8 @@ class BatchedOvercookedVecEnv:
     """
 
     def __init__(self, layout_rows, num_agents, feature="global_obs", num_envs=1, max_steps=1000, seed=0,
-                 env_index_base=0, device=None, numpy_io=False, dist_metric=0, auto_reset=True):
+                 env_index_base=0, device=None, numpy_io=False, dist_metric=0, auto_reset=True,
+                 reuse_host_buffers=False):
         if isinstance(layout_rows, str):
             layout_rows = get_layout(layout_rows)
         if feature not in FEATURE_IDS:
@@ -151,6 +152,7 @@ class BatchedOvercookedVecEnv:
         self.feature = feature
         self.max_steps = int(max_steps)
         self.numpy_io = bool(numpy_io)
+        self.reuse_host_buffers = bool(reuse_host_buffers)
         self.layout_rows = list(layout_rows)
         self.H, self.W = len(layout_rows), len(layout_rows[0])
         self.seed, self.env_index_base, self.dist_metric = int(seed), int(env_index_base), int(dist_metric)
@@ -170,6 +172,7 @@ class BatchedOvercookedVecEnv:
         self.action_space = self.single_action_space
         self.state = torch.zeros((self.state_words, self.E), dtype=torch.int32, device=self.device)
         self._closed = False
+        self._host_bufs, self._host_flip, self._obs_flip = {}, 0, 0
 
     def _create(self):
         rows = (ctypes.c_char_p * len(self.layout_rows))(*[r.encode() for r in self.layout_rows])
@@ -187,6 +190,24 @@ class BatchedOvercookedVecEnv:
     # ------------------------------------------------------------------
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _to_host(self, name, t):
+        """Device tensor -> numpy array through page-locked staging memory (a pageable
+        `.cpu()` moves the 106 MB of a 65,536-env observation at ~4 GB/s).  By default the
+        caller gets a fresh array per call, as from the reference's vec env.  With
+        ``reuse_host_buffers=True`` it gets the staging memory itself: two buffers alternate per
+        output, so an array stays valid until the call after the next one -- enough for a loop
+        that copies what it receives at once, as the reference's does
+        (agent_environment.py:36,106) -- and the copy out of the staging memory is saved."""
+        key = (name, self._host_flip if name != "obs" else self._obs_flip)
+        if name == "obs":
+            self._obs_flip ^= 1
+        buf = self._host_bufs.get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._host_bufs[key] = buf
+        buf.copy_(t, non_blocking=True)  # the caller synchronises once after queueing all its copies
+        return buf.numpy()
 
     def _new_obs(self, out):
         if out is None:
@@ -206,7 +227,7 @@ class BatchedOvercookedVecEnv:
         return t
 
     def _wrap_obs(self, obs):
-        return {OBS_KEY: obs.cpu().numpy() if self.numpy_io else obs}
+        return {OBS_KEY: self._to_host("obs", obs) if self.numpy_io else obs}
 
     # ------------------------------------------------------------------
     def reset(self, seed=None, options=None, out=None, spawn_override=None, dir_override=None):
@@ -221,7 +242,12 @@ class BatchedOvercookedVecEnv:
         so, do = self._u8(spawn_override, "spawn_override"), self._u8(dir_override, "dir_override")
         _lib.check(self._L.marl_env_reset(self._h, _ptr(self.state), _ptr(obs), _ptr(so), _ptr(do), self._stream()),
                    "marl_env_reset")
-        return self._wrap_obs(obs), {}
+        wrapped = self._wrap_obs(obs)
+        if self.numpy_io:
+            torch.cuda.current_stream(self.device).synchronize()
+            if not self.reuse_host_buffers:
+                wrapped = {OBS_KEY: wrapped[OBS_KEY].copy()}
+        return wrapped, {}
 
     def step(self, actions, out=None, prio_override=None):
         """agent_environment.py:50."""
@@ -243,7 +269,13 @@ class BatchedOvercookedVecEnv:
                                          _ptr(rew), _ptr(term), _ptr(trunc), _ptr(po), self._stream()),
                    "marl_env_step")
         if self.numpy_io:
-            return self._wrap_obs(obs), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), {}
+            out = (self._wrap_obs(obs), self._to_host("rew", rew), self._to_host("term", term),
+                   self._to_host("trunc", trunc), {})
+            self._host_flip ^= 1
+            torch.cuda.current_stream(self.device).synchronize()
+            if not self.reuse_host_buffers:
+                out = ({OBS_KEY: out[0][OBS_KEY].copy()}, out[1].copy(), out[2].copy(), out[3].copy(), out[4])
+            return out
         return {OBS_KEY: obs}, rew, term, trunc, {}
 
     def step_into(self, actions, obs, rewards, terminated, truncated, prio_override=None):
