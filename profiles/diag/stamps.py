@@ -2,13 +2,13 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 from marl_amd.env import BatchedOvercookedVecEnv
 from marl_amd.layouts import get_layout
-E, A = 65536, 2
-env = BatchedOvercookedVecEnv(get_layout("overcooked_cramped_room_v0"), A, "global_obs", E, seed=1)
+E, A = int(os.environ.get("ST_E", 65536)), int(os.environ.get("ST_A", 2))
+env = BatchedOvercookedVecEnv(get_layout(os.environ.get("ST_LAYOUT", "overcooked_cramped_room_v0")), A, os.environ.get("ST_FEAT", "global_obs"), E, seed=1)
 N, D = env.N, env.D
 obs = torch.empty((N, D), device="cuda"); rew = torch.empty(N, device="cuda")
 term = torch.empty(N, dtype=torch.bool, device="cuda"); trunc = torch.empty_like(term)
 env.reset(out=obs)
-nw = N // 64
+nw = (E + (64 // (1 if A == 1 else 2 if A == 2 else 4)) - 1) // (64 // (1 if A == 1 else 2 if A == 2 else 4))
 dbg = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
 acts = torch.randint(0, 7, (8, N), device="cuda")
 for i in range(50):
