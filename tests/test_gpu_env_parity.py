@@ -71,6 +71,53 @@ def test_rollout_parity(oracle_mod, layout, A, feature, E, max_steps, steps):
         assert total_reward > 0, "rollout never earned a reward: the test is not exercising pots"
 
 
+def _random_layout(rng, A):
+    """An enclosed grid with random contents: at least A floor cells, at most 4 pots."""
+    while True:
+        H, W = int(rng.integers(4, 10)), int(rng.integers(4, 12))
+        grid = [["#"] * W for _ in range(H)]
+        pots = 0
+        for r in range(H):
+            for c in range(W):
+                border = r in (0, H - 1) or c in (0, W - 1)
+                ch = rng.choice(list(" CUO=@#"), p=[0.0, 0.3, 0.2, 0.15, 0.15, 0.15, 0.05] if border
+                                else [0.62, 0.14, 0.05, 0.05, 0.05, 0.05, 0.04])
+                if ch == "U":
+                    if pots == 4:
+                        ch = "C"
+                    else:
+                        pots += 1
+                grid[r][c] = str(ch)
+        rows = ["".join(row) for row in grid]
+        if sum(row.count(" ") for row in rows) >= max(A, 2):
+            return rows
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_layouts(oracle_mod, case):
+    """Random kitchens (unreachable corners, pots on the border, no pot at all, ...): the lookup
+    tables the host builds for the kernel against the oracle's cell scans."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rng = np.random.default_rng(1000 + case)
+    A = int(rng.integers(1, 5))
+    rows = _random_layout(rng, A)
+    feature = ["global_obs", "local_obs", "Minimal_spatial_other_agent_aware"][case % 3]
+    E, steps = 40, 90
+    gpu = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=40, seed=case, dist_metric=case % 2)
+    ora = oracle_mod.OracleVecEnv(rows, A, feature, max_steps=40, num_envs=E, seed=case, dist_metric=case % 2)
+    np.testing.assert_array_equal(gpu.reset()[0][OBS_KEY].cpu().numpy(), ora.reset(), err_msg=str(rows))
+    for t in range(steps):
+        act = _biased_actions(rng, E * A)
+        o_g, r_g, _, tr_g, _ = gpu.step(torch.from_numpy(act))
+        o_o, r_o, _, tr_o = ora.step(act)
+        bad = np.nonzero((o_g[OBS_KEY].cpu().numpy() != o_o).any(axis=1))[0]
+        assert bad.size == 0, f"obs rows {bad[:8]} differ at step {t} on {rows}"
+        np.testing.assert_array_equal(r_g.cpu().numpy(), r_o, err_msg=f"step {t} on {rows}")
+        np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o)
+    _assert_state_equal(gpu, ora)
+
+
 @pytest.mark.parametrize("A", [1, 2, 3, 4])
 @pytest.mark.parametrize("E", [1, 17])
 def test_tiny_batches_and_constant_restarts(oracle_mod, A, E):
