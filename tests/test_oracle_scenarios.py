@@ -284,3 +284,68 @@ def test_reward_event_bookkeeping_by_hand(oracle_mod):
     r4 = np.array([0.0, 0.0, 1.0, 1.0], dtype=np.float32)
     totals, first = oracle_mod.reward_events(r4, 1, 4)
     assert totals.tolist() == [20, 1, 0, 0] and first.tolist() == [0.0, 0.0, 0.0, 0.0]
+
+
+def test_convoy_of_four_moves_as_one(oracle_mod):
+    """Four agents in a row on an open stretch of the large layout, all stepping right: each
+    follows into the cell the one ahead vacates, whatever order they are served in."""
+    rows = get_layout("large_overcooked_layout")
+    r = next(i for i, row in enumerate(rows) if "     " in row)
+    c0 = rows[r].index("     ")
+    for prio in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1]):
+        env = make(oracle_mod, [(r, c0 + k, D_UP, NONE) for k in range(4)], A=4, layout="large_overcooked_layout")
+        step(env, [RIGHT] * 4, prio=prio)
+        assert [tuple(env.agents[0, a, :2]) for a in range(4)] == [(r, c0 + k + 1) for k in range(4)], prio
+        assert all(env.agents[0, a, 2] == D_RIGHT for a in range(4))
+
+
+def test_plate_at_a_pot_that_is_not_ready_does_nothing(oracle_mod):
+    env = make(oracle_mod, [(2, 3, D_UP, PLATE), (3, 1 + 1, D_UP, NONE)])  # agent 0 faces the pot at (1,3)
+    for pot in ((0, 30), (2, 30), (3, 7)):  # empty, filling, cooking
+        env.pots[0, 0] = pot
+        _, rew, _, _ = step(env, [INTERACT, NOOP])
+        assert env.agents[0, 0, 3] == PLATE and rew.tolist() == [0.0, 0.0]
+    env.pots[0, 0] = (3, 0)  # done
+    _, rew, _, _ = step(env, [INTERACT, NOOP])
+    assert env.agents[0, 0, 3] == SOUP and tuple(env.pots[0, 0]) == (0, 30)
+    assert rew.tolist() == [np.float32(0.3), 0.0]
+
+
+def test_pot_timer_runs_only_when_full(oracle_mod):
+    env = make(oracle_mod, [(2, 2, D_UP, NONE), (3, 3, D_UP, NONE)])
+    env.pots[0, 0] = (2, 30)
+    for _ in range(5):
+        step(env, [NOOP, NOOP])
+    assert tuple(env.pots[0, 0]) == (2, 30)
+    env.pots[0, 0] = (3, 30)
+    for k in range(1, 31):
+        step(env, [NOOP, NOOP])
+        assert tuple(env.pots[0, 0]) == (3, 30 - k)
+    step(env, [NOOP, NOOP])
+    assert tuple(env.pots[0, 0]) == (3, 0)  # stays done until somebody plates it
+
+
+def test_delivery_zone_takes_only_soup(oracle_mod):
+    # the delivery zone '@' is at (4,4); an agent at (3,4) facing down is in front of it
+    for held, kept, reward in ((ONION, ONION, 0.0), (PLATE, PLATE, 0.0), (SOUP, NONE, 1.0)):
+        env = make(oracle_mod, [(3, 4, D_DOWN, held), (2, 2, D_UP, NONE)])
+        _, rew, _, _ = step(env, [INTERACT, NOOP])
+        assert env.agents[0, 0, 3] == kept
+        assert rew.tolist() == [reward, reward]  # a delivery pays every agent
+
+
+def test_closest_items_are_ordered_by_distance_then_cell(oracle_mod):
+    """Four onions lie around; agent 0 at (2,3) must list them nearest first (L1), the two at
+    equal distance in row-major cell order, each as (agent - item)."""
+    env = make(oracle_mod, [(2, 3, D_UP, NONE), (3, 4, D_UP, NONE)])
+    cells = {(1, 4): ONION, (3, 1): ONION, (2, 2): ONION, (1, 1): ONION, (3, 5): PLATE}
+    for (r, c), it in cells.items():
+        env.items[0, r * W + c] = it
+    obs = env.featurize()[0]
+    # distances from (2,3): (2,2) -> 1, (1,4) -> 2, (3,1) -> 3, (1,1) -> 3; tie: (1,1) is the earlier cell
+    want = [(0, 1), (1, -1), (1, 2), (-1, 2)]
+    assert obs[27:35].tolist() == [float(v) for pair in want for v in pair]
+    assert obs[35:37].tolist() == [-1.0, -2.0] and not obs[37:43].any()  # one plate at (3,5), rest empty
+    assert not obs[51:59].any()  # no soup anywhere
+    # the agent can move left? no: an onion lies on (2,2); right (2,4) is free, down (3,3) free, up is the pot
+    assert obs[97:101].tolist() == [1.0, 0.0, 1.0, 0.0]  # right, left, down, up
