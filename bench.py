@@ -117,8 +117,8 @@ def main():
         from marl_amd.policy import Agent
 
         torch.manual_seed(1)
-        policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1).to(dev)
-        policy.centralised_critics = None  # not evaluated on the decentralised path
+        policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
+                       build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
 
     def eager(i):
         if policy is None:

@@ -38,40 +38,43 @@ def get_rank():
 
 
 class FlatGradAllReducer:
-    """Averages gradients across ranks with ONE collective per call: gradients are packed
-    into a persistent flat buffer (~0.95 MB fp32 for the 202-input policy), all-reduced, and
-    unpacked in place.  At this size the collective is latency-bound, so one call beats one
-    per parameter."""
+    """Averages gradients across ranks with ONE collective per call: the gradients that exist
+    are packed into a persistent flat buffer (~0.95 MB fp32 for the 202-input policy),
+    all-reduced, and unpacked in place.  At this size the collective is latency-bound, so one
+    call beats one per parameter.  Parameters without a gradient (the centralised critic is
+    never trained, model.py:56-60, and is as wide as D * A * E) take no part: every rank runs
+    the same graph, so the set is the same everywhere."""
 
     def __init__(self, parameters):
         self.params = [p for p in parameters if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.active = None
+        self.flat = None
 
     @torch.no_grad()
     def __call__(self):
         w = world_size()
         if w == 1:
             return
+        active = [k for k, p in enumerate(self.params) if p.grad is not None]
+        if not active:
+            return
+        if active != self.active:
+            ref = self.params[active[0]]
+            n = sum(self.params[k].numel() for k in active)
+            self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+            self.active = active
         off = 0
-        for p in self.params:
-            k = p.numel()
-            if p.grad is None:
-                self.flat[off:off + k].zero_()
-            else:
-                self.flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
+        for k in active:
+            g = self.params[k].grad
+            self.flat[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(w)
         off = 0
-        for p in self.params:
-            k = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + k].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + k].reshape(p.shape))
-            off += k
+        for k in active:
+            g = self.params[k].grad
+            g.copy_(self.flat[off:off + g.numel()].reshape(g.shape))
+            off += g.numel()
 
 
 def all_reduce_sum_(t):

@@ -74,7 +74,7 @@ def _mlp(sizes, final_activation):
 
 
 class Agent(nn.Module):
-    def __init__(self, obs_space, action_space, num_agents=4, num_envs=1):
+    def __init__(self, obs_space, action_space, num_agents=4, num_envs=1, build_centralised=True):
         super().__init__()
         self.obs_space, self.action_space = obs_space, action_space
         self.num_agents, self.num_envs = int(num_agents), int(num_envs)
@@ -83,7 +83,11 @@ class Agent(nn.Module):
         self.actor = _ortho(nn.Linear(256, int(action_space.n)))
         self.critic = _ortho(nn.Linear(256, 1))
         # model.py:28-34: one value for the concatenated observations of every row
-        self.centralised_critics = _mlp([d * self.num_agents * self.num_envs, 512, 256, 1], final_activation=False)
+        # Its first layer is obs_dim * num_agents * num_envs wide: 54 GB of weights at 65,536 envs, and
+        # an orthogonal initialisation (a QR factorisation) of that matrix on the host.  A
+        # decentralised learner never evaluates it and may leave it out.
+        self.centralised_critics = (_mlp([d * self.num_agents * self.num_envs, 512, 256, 1], final_activation=False)
+                                    if build_centralised else None)
 
     def _trunk(self, x):
         """network(x): each Linear + ReLU pair runs as one hipBLASLt GEMM with the bias and the
@@ -91,12 +95,17 @@ class Agent(nn.Module):
         activations (250 us instead of 365 us for 131,072 x 202 -> 512)."""
         return _linear(self.network[2], _linear(self.network[0], x, True), True)
 
+    def _central(self, joint_obs):
+        if self.centralised_critics is None:
+            raise RuntimeError("this Agent was built without its centralised critic (build_centralised=False)")
+        return self.centralised_critics(joint_obs)
+
     def get_value(self, x, joint_obs=None):
         if joint_obs is not None:
             want = int(self.obs_space.shape[0]) * self.num_agents * self.num_envs
             if joint_obs.shape[1] != want:
                 raise ValueError(f"joint_obs has width {joint_obs.shape[1]}, expected {want}")
-            return self.centralised_critics(joint_obs)
+            return self._central(joint_obs)
         return _linear(self.critic, self._trunk(x), False)
 
     def get_action_and_value(self, x, action=None, joint_obs=None):
@@ -106,7 +115,7 @@ class Agent(nn.Module):
         dist = Categorical(logits=_linear(self.actor, hidden, False), validate_args=False)
         if action is None:
             action = dist.sample()
-        value = self.centralised_critics(joint_obs) if joint_obs is not None else _linear(self.critic, hidden, False)
+        value = self._central(joint_obs) if joint_obs is not None else _linear(self.critic, hidden, False)
         return action, dist.log_prob(action), dist.entropy(), value
 
     def get_prob(self, x):

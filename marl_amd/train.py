@@ -100,7 +100,16 @@ def main(argv=None):
     single_obs_dim = env.observation_spaces[0][OBS_KEY].shape
     single_action_dim = env.action_spaces[0].n
 
-    net = Agent(obs_space, action_space, num_agents=args.num_agents, num_envs=args.num_envs).to(device)
+    # model.py:28-34 always builds the centralised critic, obs_dim * num_agents * num_envs wide.  Kept for
+    # the centralised learner and whenever it is small (checkpoints then carry the reference's
+    # keys); a decentralised run with many envs leaves it out instead of allocating gigabytes.
+    central_weights = obs_space.shape[0] * args.num_agents * args.num_envs * 512
+    if args.algorithm == "cmappo" and central_weights > 2 ** 33:
+        raise SystemExit(f"--algorithm cmappo with --num-envs {args.num_envs}: the reference's centralised critic is "
+                         f"obs_dim*num_agents*num_envs = {central_weights // 512} inputs wide "
+                         f"({central_weights * 4 / 2 ** 30:.0f} GiB of weights); use fewer envs per rank")
+    net = Agent(obs_space, action_space, num_agents=args.num_agents, num_envs=args.num_envs,
+                build_centralised=args.algorithm == "cmappo" or central_weights <= 2 ** 26).to(device)
     dist_utils.broadcast_parameters(net)
     optimizer = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.95))  # main.py:294
     buffer = Buffer(single_obs_dim[0], env.config["num_agents"], args.num_envs, max_size=args.num_steps, device=device)

@@ -44,10 +44,13 @@ def _worker(rank, world, port, tmp):
     local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
     reducer = dist_utils.FlatGradAllReducer(net.parameters())
     reducer()
+    assert any(g is None for g in local)
     for p, g in zip(net.parameters(), local):
-        mine = torch.zeros_like(p) if g is None else g
+        if g is None:
+            assert p.grad is None  # parameters without a gradient take no part in the collective
+            continue
         both = [torch.zeros_like(p) for _ in range(world)]
-        dist.all_gather(both, mine)
+        dist.all_gather(both, g)
         torch.testing.assert_close(p.grad, sum(both) / world, rtol=1e-6, atol=1e-7)
 
     # --- env sharding: rank r simulates envs [r*E, (r+1)*E) of one 2E-env job
