@@ -160,3 +160,21 @@ def test_policy_forward_and_gradients_match_plain_layers():
     with torch.no_grad():
         _, lp_n, ent_n, v_n = net.get_action_and_value(obs, actions)
         assert torch.equal(lp_n, lp_p) and torch.equal(v_n, v_p) and torch.equal(net.get_value(obs), v_p)
+
+
+def test_saved_policy_plays_through_the_evaluate_entry_point(tmp_path):
+    """train --save writes a state_dict with the reference's key names; evaluate loads it (and
+    ignores the centralised critic) and plays whole episodes."""
+    from marl_amd import evaluate
+
+    E, A, T = 16, 2, 32
+    _run(["--num-agents", str(A), "--num-envs", str(E), "--layout", "overcooked_cramped_room_v0", "--num-steps", str(T),
+          "--total-steps", str(E * A * T * 2), "--ppo-epoch", "1", "--max-steps", "40", "--data-path", str(tmp_path / "d"),
+          "--save", "--save-path", str(tmp_path / "models"), "--seed", "2"])
+    path = tmp_path / "models" / "decentralised_policy_2_agents_overcooked_cramped_room_v0_seed_2.pth"
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert {"network.0.weight", "network.2.bias", "actor.weight", "critic.bias", "centralised_critics.4.weight"} <= set(sd)
+    out = evaluate.main(["--model-path", str(path), "--num-agents", str(A), "--layout", "overcooked_cramped_room_v0",
+                         "--num-envs", "32", "--episodes", "2", "--max-steps", "60"])
+    assert len(out) == 2 and all(np.isfinite(list(r.values())).all() for r in out)
+    assert all(0.0 <= r["deliveries"] <= 60 for r in out)
