@@ -153,6 +153,23 @@ int marl_reward_events(const float *d_rewards, int num_envs, int num_agents, uin
                        double *d_first_rows, void *d_workspace, void *stream);
 size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
 
+/*
+ * The sampling half of MAPPO.act (agents/MAPPO.py:58-77 -> model.py:52-56): for every row of
+ * d_logits (float32 [num_rows][num_actions], row-major) draw an action from
+ * Categorical(logits=row) and report its log-probability and the distribution's entropy.
+ *   d_actions  int64 [num_rows];  d_logprob, d_entropy  float32 [num_rows] or NULL.
+ *   seed, d_counter, row_index_base: the uniform of a row comes from a counter RNG keyed by
+ *   (seed, *d_counter, row_index_base + row).  d_counter is a uint64 in DEVICE memory (NULL = 0)
+ *   that the caller advances between calls (it is read, not written, here: a launch captured
+ *   in a hipGraph draws fresh numbers on every replay as long as the counter moves).
+ * log_prob and entropy are the float32 formulas of torch.distributions.Categorical
+ * (logits - logsumexp; -sum p * log p); they agree with PyTorch's to the last bits, not bit
+ * for bit (another exp / log implementation).
+ */
+int marl_sample_categorical(const float *d_logits, int num_rows, int num_actions, uint64_t seed,
+                            const uint64_t *d_counter, int64_t row_index_base, int64_t *d_actions,
+                            float *d_logprob, float *d_entropy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,40 @@
+"""Categorical sampling of the rollout on the GPU (libmarl_amd.so `marl_sample_categorical`):
+the sampling half of ``MAPPO.act`` (agents/MAPPO.py:58-77, model.py:52-56) as one launch
+instead of the dozen small tensor ops behind ``Categorical(logits=...).sample()``,
+``.log_prob()`` and ``.entropy()``."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class CategoricalSampler:
+    """Draws from Categorical(logits=row) for every row.  The uniform behind row r of call c
+    comes from a counter RNG keyed by (seed, c, row_index_base + r); the call counter lives on
+    the device and is advanced by a captured op, so a launch replayed from a hipGraph keeps
+    drawing fresh numbers."""
+
+    def __init__(self, seed: int, row_index_base: int = 0, device="cuda"):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.row_index_base = int(row_index_base)
+        self.device = torch.device(device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def sample(self, logits: torch.Tensor, want_entropy: bool = True):
+        if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
+            raise ValueError("logits must be a float32 [rows, actions] tensor on the GPU")
+        logits = logits.contiguous()
+        n, k = logits.shape
+        actions = torch.empty(n, dtype=torch.int64, device=logits.device)
+        logprob = torch.empty(n, dtype=torch.float32, device=logits.device)
+        entropy = torch.empty(n, dtype=torch.float32, device=logits.device) if want_entropy else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, self.seed, p(self.counter), self.row_index_base,
+                                                      p(actions), p(logprob), p(entropy), stream),
+                   "marl_sample_categorical")
+        self.counter.add_(1)
+        return actions, logprob, entropy

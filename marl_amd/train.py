@@ -65,6 +65,8 @@ def build_parser():
                                ("--mixing-embed-dim", int, 32), ("--num-episodes", int, 1000), ("--tau", float, 0.005),
                                ("--batch-size-sac", int, 32)):
         p.add_argument(name, type=typ, default=default, help="accepted for compatibility, unused (QMIX / SARSA / SAC only)")
+    p.add_argument("--sampler", choices=["fused", "torch"], default="fused",
+                   help="rollout action sampling: one HIP launch with a counter RNG, or torch.distributions")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
                    help="replay rollout steps from hipGraphs (auto: single rank and at most 16,384 rows per launch)")
     return p
@@ -111,6 +113,8 @@ def main(argv=None):
     net = Agent(obs_space, action_space, num_agents=args.num_agents, num_envs=args.num_envs,
                 build_centralised=args.algorithm == "cmappo" or central_weights <= 2 ** 26).to(device)
     dist_utils.broadcast_parameters(net)
+    if args.sampler == "fused":
+        net.use_fused_sampling(args.seed, row_index_base=rank * args.num_envs * args.num_agents)
     optimizer = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.95))  # main.py:294
     buffer = Buffer(single_obs_dim[0], env.config["num_agents"], args.num_envs, max_size=args.num_steps, device=device)
     # main.py:291,303: the centralised learner is reached only through --algorithm cmappo

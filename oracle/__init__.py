@@ -189,3 +189,46 @@ def reward_events(rewards, num_envs, num_agents):
         float((head == np.float32(0.1)).any()),
     ], dtype=np.float64)
     return totals, first
+
+
+def _mix32(x):
+    x = np.asarray(x, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    x = x ^ (x >> np.uint64(16)); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xFFFFFFFF)
+    x = x ^ (x >> np.uint64(15)); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xFFFFFFFF)
+    return x ^ (x >> np.uint64(16))
+
+
+def sample_categorical(logits, seed, counter, row_index_base=0):
+    """Categorical(logits=row).sample / log_prob / entropy (model.py:52-56) with the counter RNG of
+    the GPU path, numpy float32.  Returns (actions int64, log_prob f32, entropy f32)."""
+    l = np.ascontiguousarray(logits, dtype=np.float32)
+    n, k = l.shape
+    m = l.max(axis=1)
+    e = np.exp((l - m[:, None]).astype(np.float32)).astype(np.float32)
+    S = np.zeros(n, np.float32)
+    for j in range(k):
+        S = (S + e[:, j]).astype(np.float32)
+    lse = (m + np.log(S).astype(np.float32)).astype(np.float32)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = _mix32((seed & 0xFFFFFFFF) + 0x9E3779B9)
+    key = _mix32(int(key) ^ (seed >> 32))
+    c = int(counter)
+    r = _mix32(int(key) ^ (c & 0xFFFFFFFF))
+    r = _mix32(int(r) ^ (c >> 32) ^ 0x85EBCA6B)
+    rows = np.arange(n, dtype=np.uint64) + np.uint64(row_index_base)
+    r = _mix32(np.uint64(int(r)) ^ (rows & np.uint64(0xFFFFFFFF)))
+    r = _mix32(r + (rows >> np.uint64(32)))
+    u = ((r >> np.uint64(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+    target = (u * S).astype(np.float32)
+    cum = np.zeros(n, np.float32)
+    act = np.full(n, k - 1, np.int64)
+    found = np.zeros(n, bool)
+    ent = np.zeros(n, np.float32)
+    for j in range(k):
+        cum = (cum + e[:, j]).astype(np.float32)
+        hit = ~found & (cum > target)
+        act[hit] = j
+        found |= hit
+        ent = (ent - ((e[:, j] / S).astype(np.float32) * (l[:, j] - lse).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    lp = (l[np.arange(n), act] - lse).astype(np.float32)
+    return act, lp, ent
