@@ -119,6 +119,7 @@ def main():
         torch.manual_seed(1)
         policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
                        build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
+        policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
 
     def eager(i):
         if policy is None:
