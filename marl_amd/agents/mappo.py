@@ -29,7 +29,7 @@ class MAPPO:
     def __init__(self, env, optimzer, policy, buffer, single_agent_obs, single_agent_action, batch_size=1,
                  num_mini_batches=4, num_agents=4, ppo_epoch=10, clip_param=0.2, value_loss_coef=0.5,
                  entropy_coef=0.01, max_grad_norm=0.5, gamma=0.99, lam=0.95, save_path=None, log_dir=None,
-                 log=False, args=None, shuffle="device", writer=None):
+                 log=False, args=None, shuffle="device", writer=None, graph_update="off"):
         self.env, self.optimizer, self.policy, self.buffer = env, optimzer, policy, buffer
         self.num_agents = num_agents
         self.single_agent_obs, self.single_agent_action = single_agent_obs, single_agent_action
@@ -46,6 +46,15 @@ class MAPPO:
         self.num_gradient_steps = 0
         self.last_stats = {}
         self._reducer = dist_utils.FlatGradAllReducer(policy.parameters()) if policy is not None else None
+        # "auto": replay the minibatch step (forward, backward, clip, Adam) from a hipGraph when it is
+        # launch-bound; single rank only (the gradient all-reduce sits in the middle of the step)
+        small = batch_size // max(num_mini_batches, 1) <= 65536
+        self._graph_update = (graph_update == "on" or (graph_update == "auto" and small)) \
+            and dist_utils.world_size() == 1 and self.device.type == "cuda" and optimzer is not None
+        self._g = None
+        if self._graph_update:
+            for group in optimzer.param_groups:  # the step counter must live on the device to be captured
+                group["capturable"] = True
 
     # ------------------------------------------------------------------ acting
     def act(self, obs):
@@ -74,6 +83,55 @@ class MAPPO:
         return self.policy.get_value(next_obs).reshape(1, rows)  # agents/MAPPO.py:133
 
     # ------------------------------------------------------------------ update
+    def _minibatch_step(self, mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target):
+        """agents/MAPPO.py:167-209 for one minibatch; returns the six logged statistics."""
+        _, newlogprob, entropy, newvalue = self.policy.get_action_and_value(b_obs[mb], b_actions_f[mb].long())
+        logratio = newlogprob - b_logprobs[mb]
+        ratio = logratio.exp()
+        mb_adv = b_advantages[mb]
+        pg_loss = torch.max(-mb_adv * ratio,
+                            -mb_adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        v_loss = self.compute_value_loss(b_value_target[mb], newvalue.squeeze())
+        entropy_loss = entropy.mean()
+        loss = pg_loss - self.entropy_coef * entropy_loss + v_loss * self.value_loss_coef
+
+        self.optimizer.zero_grad()
+        loss.backward()
+        self._reducer()  # RCCL: one flat all-reduce, no-op on a single rank
+        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+
+        with torch.no_grad():
+            return torch.stack([v_loss, pg_loss, entropy_loss, ((ratio - 1) - logratio).mean(), (-logratio).mean(),
+                                ((ratio - 1.0).abs() > self.clip_param).float().mean()]).double()
+
+    def _replay_minibatch(self, mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target):
+        """The same step replayed from a hipGraph.  Captured once, after the first eager update has
+        created the optimizer state; inputs are read from fixed addresses (the rollout store and
+        three staging tensors), so a replay needs one index copy and one launch."""
+        g = self._g
+        if g is None or g["obs"] != b_obs.data_ptr():
+            total = b_logprobs.numel()
+            st = {"obs": b_obs.data_ptr(),
+                  "mb": torch.zeros(self.mini_batch_size, dtype=torch.int64, device=self.device),
+                  "adv": torch.empty(total, dtype=torch.float32, device=self.device),
+                  "ret": torch.empty(total, dtype=torch.float32, device=self.device)}
+            st["adv"].copy_(b_advantages); st["ret"].copy_(b_value_target)
+            st["src"] = (b_advantages.data_ptr(), b_value_target.data_ptr())
+            st["mb"].copy_(mb)
+            torch.cuda.current_stream(self.device).synchronize()
+            st["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["graph"], capture_error_mode="thread_local"):
+                st["out"] = self._minibatch_step(st["mb"], b_obs, b_actions_f, b_logprobs, st["adv"], st["ret"])
+            self._g = g = st
+        src = (b_advantages.data_ptr(), b_value_target.data_ptr())
+        if g["src"] != src:  # a new update: advantages and targets of this rollout
+            g["adv"].copy_(b_advantages); g["ret"].copy_(b_value_target)
+            g["src"] = src
+        g["mb"].copy_(mb)
+        g["graph"].replay()
+        return g["out"]
+
     def update(self, next_obs):
         """agents/MAPPO.py:116-233."""
         buf = self.buffer
@@ -84,7 +142,7 @@ class MAPPO:
         obs_shape = tuple(self.env.single_observation_space.shape)
         b_obs = buf.obs_buff.reshape((-1,) + obs_shape)
         b_logprobs = buf.logprobs_buff.reshape(-1)
-        b_actions = buf.actions_buff.reshape(-1).long()
+        b_actions_f = buf.actions_buff.reshape(-1)  # stored as float32 like the reference's buffer
         b_advantages = advantages.reshape(-1)
         b_value_target = value_target.reshape(-1)
         total = b_logprobs.numel()
@@ -102,26 +160,10 @@ class MAPPO:
                 perm = torch.randperm(total, device=self.device)
             for start in range(0, total, self.mini_batch_size):
                 mb = perm[start:min(start + self.mini_batch_size, total)]
-                _, newlogprob, entropy, newvalue = self.policy.get_action_and_value(b_obs[mb], b_actions[mb])
-                logratio = newlogprob - b_logprobs[mb]
-                ratio = logratio.exp()
-                mb_adv = b_advantages[mb]
-                pg_loss = torch.max(-mb_adv * ratio,
-                                    -mb_adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-                v_loss = self.compute_value_loss(b_value_target[mb], newvalue.squeeze())
-                entropy_loss = entropy.mean()
-                loss = pg_loss - self.entropy_coef * entropy_loss + v_loss * self.value_loss_coef
-
-                self.optimizer.zero_grad()
-                loss.backward()
-                self._reducer()  # RCCL: one flat all-reduce, no-op on a single rank
-                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-                self.optimizer.step()
-
-                with torch.no_grad():
-                    sums += torch.stack([v_loss, pg_loss, entropy_loss, ((ratio - 1) - logratio).mean(),
-                                         (-logratio).mean(),
-                                         ((ratio - 1.0).abs() > self.clip_param).float().mean()]).double()
+                if self._graph_update and self.num_gradient_steps > 0 and mb.numel() == self.mini_batch_size:
+                    sums += self._replay_minibatch(mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target)
+                else:
+                    sums += self._minibatch_step(mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target)
                 count += 1
         self.num_gradient_steps += 1
         stats = (sums / max(count, 1)).tolist()  # one sync per update

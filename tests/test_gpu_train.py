@@ -178,3 +178,35 @@ def test_saved_policy_plays_through_the_evaluate_entry_point(tmp_path):
                          "--num-envs", "32", "--episodes", "2", "--max-steps", "60"])
     assert len(out) == 2 and all(np.isfinite(list(r.values())).all() for r in out)
     assert all(0.0 <= r["deliveries"] <= 60 for r in out)
+
+
+def test_graph_replayed_update_follows_the_eager_one(tmp_path):
+    """Same seeds, rollouts and sampler; two updates, the second one's minibatch steps launched
+    eagerly in one run and replayed from a hipGraph in the other.  Both see identical data (the
+    first update is eager in both), the replay runs the same kernels, and only Adam's step
+    counter moving to the device touches the last bits."""
+    import marl_amd.agents.mappo as m
+
+    finals = {}
+    for mode in ("off", "on"):
+        keep = {}
+        orig = m.MAPPO.update
+
+        def upd(self, obs, _orig=orig, _keep=keep):
+            _orig(self, obs)
+            _keep["p"] = torch.cat([p.detach().reshape(-1) for n, p in self.policy.named_parameters()
+                                    if not n.startswith("centralised")]).cpu()
+            _keep["stats"] = dict(self.last_stats)
+
+        m.MAPPO.update = upd
+        try:
+            _run(["--num-agents", "2", "--num-envs", "32", "--layout", "overcooked_cramped_room_v0", "--num-steps", "32",
+                  "--num-minibatches", "4", "--total-steps", str(32 * 2 * 32 * 2), "--ppo-epoch", "2", "--max-steps", "50",
+                  "--data-path", str(tmp_path / mode), "--seed", "7", "--graph-update", mode])
+        finally:
+            m.MAPPO.update = orig
+        finals[mode] = keep
+    assert all(np.isfinite(v) for v in finals["on"]["stats"].values())
+    a, b = finals["off"]["p"], finals["on"]["p"]
+    assert torch.isfinite(b).all() and not torch.equal(b, torch.zeros_like(b))
+    torch.testing.assert_close(b, a, rtol=0, atol=1e-5)
