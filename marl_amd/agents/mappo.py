@@ -117,17 +117,17 @@ class MAPPO:
                   "adv": torch.empty(total, dtype=torch.float32, device=self.device),
                   "ret": torch.empty(total, dtype=torch.float32, device=self.device)}
             st["adv"].copy_(b_advantages); st["ret"].copy_(b_value_target)
-            st["src"] = (b_advantages.data_ptr(), b_value_target.data_ptr())
+            st["update"] = self.num_gradient_steps
             st["mb"].copy_(mb)
             torch.cuda.current_stream(self.device).synchronize()
             st["graph"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st["graph"], capture_error_mode="thread_local"):
                 st["out"] = self._minibatch_step(st["mb"], b_obs, b_actions_f, b_logprobs, st["adv"], st["ret"])
             self._g = g = st
-        src = (b_advantages.data_ptr(), b_value_target.data_ptr())
-        if g["src"] != src:  # a new update: advantages and targets of this rollout
+        if g["update"] != self.num_gradient_steps:  # a new update: advantages and targets of this rollout
+            # (never keyed on the tensors' addresses: the allocator hands the same block out again)
             g["adv"].copy_(b_advantages); g["ret"].copy_(b_value_target)
-            g["src"] = src
+            g["update"] = self.num_gradient_steps
         g["mb"].copy_(mb)
         g["graph"].replay()
         return g["out"]

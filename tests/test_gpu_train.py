@@ -210,3 +210,32 @@ def test_graph_replayed_update_follows_the_eager_one(tmp_path):
     a, b = finals["off"]["p"], finals["on"]["p"]
     assert torch.isfinite(b).all() and not torch.equal(b, torch.zeros_like(b))
     torch.testing.assert_close(b, a, rtol=0, atol=1e-5)
+
+
+def test_graph_replayed_update_sees_each_rollouts_advantages(tmp_path):
+    """The replayed step reads advantages and value targets from staging tensors: they must hold
+    the numbers of the CURRENT update every time (freshly computed tensors often come back at the
+    address the previous ones had, so nothing may be keyed on addresses)."""
+    import marl_amd.agents.mappo as m
+
+    seen = []
+    orig_update, orig_gae = m.MAPPO.update, m.MAPPO.compute_gae
+
+    def gae(self, *a, **k):
+        out = orig_gae(self, *a, **k)
+        self._last = (out[0].reshape(-1).clone(), out[1].reshape(-1).clone())
+        return out
+
+    def upd(self, obs):
+        orig_update(self, obs)
+        if self._g is not None:
+            seen.append(torch.equal(self._g["adv"], self._last[0]) and torch.equal(self._g["ret"], self._last[1]))
+
+    m.MAPPO.update, m.MAPPO.compute_gae = upd, gae
+    try:
+        _run(["--num-agents", "2", "--num-envs", "16", "--layout", "overcooked_cramped_room_v0", "--num-steps", "32",
+              "--num-minibatches", "4", "--total-steps", str(16 * 2 * 32 * 6), "--ppo-epoch", "2", "--max-steps", "50",
+              "--data-path", str(tmp_path), "--seed", "3", "--graph-update", "on"])
+    finally:
+        m.MAPPO.update, m.MAPPO.compute_gae = orig_update, orig_gae
+    assert len(seen) == 5 and all(seen)
