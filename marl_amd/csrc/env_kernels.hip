@@ -864,9 +864,9 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     using G = FeatGeom<A, FEAT>;
     // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
     static const int waves_req = [] { const char* v = getenv("MARL_AMD_WAVES"); return v ? atoi(v) : 4; }();  // tuning aid
-    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4 || waves_req == 8) ? waves_req : 4;
+    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4) ? waves_req : 4;  // the kernel is bounded to 256 threads
     constexpr int RPW = 64 / lanes_per_env(A) * A;  // rows per wave
-    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * RPW * G::D > (waves_req == 8 ? 128 : 64) * 1024) waves >>= 1;
+    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * RPW * G::D > 64 * 1024) waves >>= 1;
     const size_t lds = (size_t)P.tab_bytes + (size_t)waves * RPW * G::D;
     static size_t configured[64] = {0};  // per instantiation and device
     int dev = 0;
