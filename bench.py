@@ -45,7 +45,7 @@ def cpu_baseline(layout_rows, A, feature, E, seed, threads):
     for i in range(4):
         env.step(acts[i % 8])
     per = (time.perf_counter() - t0) / 4
-    steps = int(max(8, min(2000, 12.0 / max(per, 1e-6))))
+    steps = int(max(8, min(6000, 15.0 / max(per, 1e-6))))  # about 15 s of host work
     t0 = time.perf_counter()
     for i in range(steps):
         env.step(acts[i % 8])
