@@ -10,9 +10,9 @@
 // per lane per iteration -> 4 floats -> one 16-byte store, so every store instruction writes
 // 1 KiB of consecutive HBM bytes.  The float32 observation write is >90 % of the algorithmic
 // bytes of this path, and at 65,536 envs the whole launch is a single round of waves: the
-// simulation does not hide behind the store stream, it delays it, and what it costs is its
-// instruction count (each wave runs a dependent chain at about one VALU instruction per 8
-// cycles, two waves fill a SIMD).  Hence the style below: everything an agent needs to know
+// simulation does not hide behind the store stream, it delays it, and what it costs is the
+// length of the dependent chain a wave runs before its first store (about one VALU
+// instruction per 8 cycles, plus every LDS round trip on the way).  Hence the style below: everything an agent needs to know
 // about the cells around it comes from 16-byte LDS reads of per-floor-cell records built on the
 // host, rule chains are host-built decision tables, and the dynamics are selects, not branches.
 // An env takes 1, 2 or 4 adjacent lanes (three agents leave the fourth idle), so its lanes
