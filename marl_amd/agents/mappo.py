@@ -151,9 +151,9 @@ class MAPPO:
 
         sums = torch.zeros(6, dtype=torch.float64, device=self.device)  # v, pg, ent, kl, old_kl, clipfrac
         count = 0
+        idx = np.arange(total)  # agents/MAPPO.py:156: shuffled in place epoch after epoch, never re-sorted
         for _ in range(self.ppo_epoch):
             if self.shuffle == "numpy":
-                idx = np.arange(total)
                 np.random.shuffle(idx)
                 perm = torch.from_numpy(idx).to(self.device)
             else:
