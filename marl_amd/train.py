@@ -147,7 +147,8 @@ def main(argv=None):
         for key in ("frequency_delivery_per_episode", "frequency_plated_per_episode",
                     "frequency_ingredient_in_pot_per_episode"):
             write_csv(os.path.join(folder, f"{stem}_{key}_seed_{args.seed}.csv"), freq[key])
-        write_csv(os.path.join(folder, f"{stem}_returns_all_envs_seed_{args.seed}.csv"), freq["episode_return_all_envs"])
+        # not "..._returns_...": plot.py:112 reads every file of the folder whose name contains its keyword
+        write_csv(os.path.join(folder, f"{stem}_all_envs_episode_return_seed_{args.seed}.csv"), freq["episode_return_all_envs"])
         with open(os.path.join(folder, f"{stem}_args_seed_{args.seed}.txt"), "w") as f:
             for k, v in vars(args).items():
                 f.write(f"{k}: {v}\n")
