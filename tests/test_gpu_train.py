@@ -239,3 +239,26 @@ def test_graph_replayed_update_sees_each_rollouts_advantages(tmp_path):
     finally:
         m.MAPPO.update, m.MAPPO.compute_gae = orig_update, orig_gae
     assert len(seen) == 5 and all(seen)
+
+
+def test_host_array_mode_fresh_arrays_and_staging_reuse():
+    """numpy_io hands out fresh arrays by default; with reuse_host_buffers the caller gets the
+    page-locked staging memory, which stays valid until the call after the next one."""
+    from marl_amd.env import OBS_KEY, make_env, make_vector_env
+
+    env = make_env(2, "overcooked_cramped_room_v0", "global_obs", max_steps=50)
+    acts = np.random.default_rng(0).integers(0, 7, size=(6, 16))
+    fresh = make_vector_env(8, env, numpy_io=True, seed=4)
+    staged = make_vector_env(8, env, numpy_io=True, seed=4, reuse_host_buffers=True)
+    kept_f, kept_s, copies = [], [], []
+    for t in range(6):
+        of, rf, _, _, _ = fresh.step(acts[t])
+        os_, rs, _, _, _ = staged.step(acts[t])
+        np.testing.assert_array_equal(of[OBS_KEY], os_[OBS_KEY])
+        np.testing.assert_array_equal(rf, rs)
+        kept_f.append(of[OBS_KEY]); kept_s.append(os_[OBS_KEY]); copies.append(of[OBS_KEY].copy())
+    for t in range(6):
+        np.testing.assert_array_equal(kept_f[t], copies[t])  # fresh arrays are never written again
+    np.testing.assert_array_equal(kept_s[5], copies[5])
+    np.testing.assert_array_equal(kept_s[4], copies[4])      # still valid one call later
+    assert kept_s[3] is not kept_s[5] and np.shares_memory(kept_s[3], kept_s[5])  # two buffers alternate
