@@ -1,4 +1,4 @@
-"""The ctypes stub printed in INTEGRATION.md section 2 is run as it stands."""
+"""The ctypes stub that the integration guide at the repository root prints is run as it stands."""
 import os
 import re
 
