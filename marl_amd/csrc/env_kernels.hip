@@ -15,8 +15,10 @@
 // instruction per 8 cycles, plus every LDS round trip on the way).  Hence the style below: everything an agent needs to know
 // about the cells around it comes from 16-byte LDS reads of per-floor-cell records built on the
 // host, rule chains are host-built decision tables, and the dynamics are selects, not branches.
-// An env takes 1, 2 or 4 adjacent lanes (three agents leave the fourth idle), so its lanes
-// share a wave and the wave's row image is private to it.
+// An env takes 1, 2 or 4 adjacent lanes (with three agents the fourth has no row), so its lanes
+// share a wave and the wave's row image is private to it.  With three or four agents replaying
+// everything in every lane costs too much: there the env's four lanes split the step and
+// trade results through DPP moves (step_env_quad).
 //
 // Replaces, for the reference's drivers, the third-party env.step()/reset() reached at
 // agent_environment.py:34,50,88 and the feature composition of
