@@ -108,6 +108,9 @@ int marl_env_featurize(marl_env_t *env, void *d_state, float *d_obs, void *strea
  *   d_pots   int32 [E][NP][2] = (onion count, cooking timer)
  *   d_items  uint8 [E][H*W]  item lying on each floor / counter cell
  *   d_misc   int32 [E][2]    = (t, RNG draw counter)
+ * Import does not judge the snapshot: codes are masked to their field widths and an agent placed
+ * off the grid or off the floor goes to the first floor cell.  Callers validate beforehand (the
+ * Python host does: marl_amd/env.py, _validate_snapshot).
  */
 int marl_env_export_state(marl_env_t *env, const void *d_state, int32_t *d_agents, int32_t *d_pots,
                           uint8_t *d_items, int32_t *d_misc, void *stream);

@@ -331,8 +331,12 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, int W, con
         uint32_t aw = 0;
         for (int h = 0; h < 2 && 2 * k + h < A; ++h) {
             const int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
-            const uint32_t fi = aux[AUX_FIDX_OF_CELL + (uint32_t)(o[0] * W + o[1])];
-            const uint32_t v = fi | ((uint32_t)o[2] << 8) | ((uint32_t)o[3] << 10);
+            // a position off the grid or off the floor is replaced by the first floor cell: the
+            // lookup must stay inside the table whatever the caller uploaded
+            const bool inside = o[0] >= 0 && o[1] >= 0 && o[1] < W && o[0] * W + o[1] < ncell;
+            uint32_t fi = inside ? aux[AUX_FIDX_OF_CELL + (uint32_t)(o[0] * W + o[1])] : 0xFFu;
+            fi = fi == 0xFFu ? 0u : fi;
+            const uint32_t v = fi | (((uint32_t)o[2] & 3u) << 8) | (((uint32_t)o[3] & 3u) << 10);
             aw |= v << (16 * h);
         }
         st[(w++) * E + e] = aw;
