@@ -118,6 +118,43 @@ def test_random_layouts(oracle_mod, case):
     _assert_state_equal(gpu, ora)
 
 
+CROWDED = [
+    # a corridor and two small rooms: agents queue, contest cells, try to swap and get pushed back in chains
+    (["#######", "#     #", "#######"], 3), (["#######", "#     #", "#######"], 4),
+    (["#####", "#   #", "# U #", "#   #", "#####"], 4), (["####", "#  #", "#  #", "####"], 3),
+    (["#OU@=#", "#    #", "#C  C#", "######"], 4),
+]
+
+
+@pytest.mark.parametrize("rows,A", CROWDED)
+@pytest.mark.parametrize("replay", [False, True])
+def test_crowded_floors(oracle_mod, rows, A, replay):
+    """Three and four agents with hardly any room: the serving order, the no-swap rule and the
+    retreat from occupied cells (several in a row) on nearly every step; with drawn and with
+    caller-given serving orders."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    E, steps = 150, 120
+    gpu = BatchedOvercookedVecEnv(rows, A, "local_obs", E, max_steps=50, seed=5)
+    ora = oracle_mod.OracleVecEnv(rows, A, "local_obs", max_steps=50, num_envs=E, seed=5)
+    np.testing.assert_array_equal(gpu.reset()[0][OBS_KEY].cpu().numpy(), ora.reset())
+    rng = np.random.default_rng(A * 7 + len(rows))
+    moved = 0
+    for t in range(steps):
+        act = rng.choice(7, size=E * A, p=[0.22, 0.22, 0.22, 0.22, 0.06, 0.0, 0.06]).astype(np.int64)
+        prio = rng.integers(0, 256, size=E * A).astype(np.uint8) if replay else None
+        before = ora.agents[:, :, :2].copy()
+        o_g, r_g, _, tr_g, _ = gpu.step(torch.from_numpy(act), prio_override=None if prio is None else torch.from_numpy(prio))
+        o_o, r_o, _, tr_o = ora.step(act, prio_override=prio)
+        moved += int((ora.agents[:, :, :2] != before).any(axis=2).sum())
+        bad = np.nonzero((o_g[OBS_KEY].cpu().numpy() != o_o).any(axis=1))[0]
+        assert bad.size == 0, f"obs rows {bad[:8]} differ at step {t} on {rows}"
+        np.testing.assert_array_equal(r_g.cpu().numpy(), r_o)
+        np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o)
+        _assert_state_equal(gpu, ora)
+    assert moved > steps * E // 4, "agents hardly moved: the test is not exercising the collision rules"
+
+
 @pytest.mark.parametrize("A", [1, 2, 3, 4])
 @pytest.mark.parametrize("E", [1, 17])
 def test_tiny_batches_and_constant_restarts(oracle_mod, A, E):
