@@ -65,6 +65,19 @@ class MAPPO:
                 return self.policy.get_action_and_value(obs, joint_obs=obs.view(1, -1))
             return self.policy.get_action_and_value(obs)
 
+    def act_into(self, obs, step):
+        """`act` + the learner-side half of `add_to_buffer` for row `step` of the rollout store:
+        log-probabilities and values are written into their rows by the kernels that produce them,
+        the actions are stored as float32 like the reference does (buffer.py:12).  Returns the
+        int64 actions for the env.  Decentralised critic with fused sampling only."""
+        buf = self.buffer
+        actions = self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step])
+        buf.actions_buff[step].copy_(actions)
+        return actions
+
+    def can_act_into(self):
+        return not self.centralised and getattr(self.policy, "sampler", None) is not None
+
     def add_to_buffer(self, obs, actions, rewards, dones, logprobs, values):
         self.buffer.add(obs, actions, rewards, dones, logprobs, values)
 

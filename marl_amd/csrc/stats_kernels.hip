@@ -1,5 +1,6 @@
 // Per-step reward-event bookkeeping of the rollout driver (agent_environment.py:66-76) as two
-// small launches instead of a dozen tensor ops, and for EVERY env instead of the first two rows.
+// small launches (one when a single workgroup covers the rows) instead of a dozen tensor ops,
+// and for EVERY env instead of the first two rows.
 //
 // The reference classifies a step by comparing float32 rewards with constants: any reward >= 1
 // is a delivery, == 0.3 a plating, == 0.1 an onion put into a pot (rows 0..1 only, whatever the
@@ -18,9 +19,29 @@ int reward_event_chunks(int N) {
     return c < 1 ? 1 : c > 256 ? 256 : c;
 }
 
-// pass 1: block c scans envs c, c + C, ... and writes its four sums to partial[c][4]
+// rows 0..1 the way the reference counts them: rewards[0:2].mean() in float32, accumulated as a
+// Python float (agent_environment.py:76), and the three event flags of those rows
+__device__ __forceinline__ void first_rows_update(const float* __restrict__ rewards, int N, double* __restrict__ first_rows) {
+    const int n = N < 2 ? N : 2;
+    float sum = 0.0f;
+    bool d = false, p = false, o = false;
+    for (int j = 0; j < n; ++j) {
+        const float r = rewards[j];
+        sum = __fadd_rn(sum, r);
+        d |= r >= 1.0f; p |= r == 0.3f; o |= r == 0.1f;
+    }
+    first_rows[0] += (double)__fdiv_rn(sum, (float)n);
+    first_rows[1] += d ? 1.0 : 0.0;
+    first_rows[2] += p ? 1.0 : 0.0;
+    first_rows[3] += o ? 1.0 : 0.0;
+}
+
+// pass 1: block c scans envs c, c + C, ... and writes its four sums to partial[c][4].  Launched
+// as a single block with `totals` set it is the whole job: the sums go straight to the totals
+// and lane 4 does the first-rows part.
 __global__ void __launch_bounds__(EVENT_BLOCK)
-reward_events_partial_kernel(const float* __restrict__ rewards, int E, int A, uint64_t* __restrict__ partial) {
+reward_events_partial_kernel(const float* __restrict__ rewards, int E, int A, uint64_t* __restrict__ partial,
+                             uint64_t* __restrict__ totals, double* __restrict__ first_rows) {
     uint32_t tenths = 0, deliv = 0, plate = 0, pot = 0;  // per lane: at most E/blocks envs, far below 2^32
     for (int e = blockIdx.x * EVENT_BLOCK + threadIdx.x; e < E; e += gridDim.x * EVENT_BLOCK) {
         bool d = false, p = false, o = false;
@@ -48,7 +69,10 @@ reward_events_partial_kernel(const float* __restrict__ rewards, int E, int A, ui
     if (threadIdx.x < 4) {
         uint64_t s = 0;
         for (int w = 0; w < EVENT_BLOCK / 64; ++w) s += part[w][threadIdx.x];
-        partial[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+        if (totals) totals[threadIdx.x] += s;
+        else partial[(size_t)blockIdx.x * 4 + threadIdx.x] = s;
+    } else if (threadIdx.x == 4 && totals && first_rows) {
+        first_rows_update(rewards, E * A, first_rows);
     }
 }
 
@@ -61,26 +85,20 @@ __global__ void reward_events_finish_kernel(const float* __restrict__ rewards, i
         for (int c = 0; c < C; ++c) s += partial[(size_t)c * 4 + k];
         totals[k] += s;
     } else if (k == 4 && first_rows) {
-        // rewards[0:2].mean() in float32, then accumulated as a Python float (agent_environment.py:76)
-        const int n = N < 2 ? N : 2;
-        float sum = 0.0f;
-        bool d = false, p = false, o = false;
-        for (int j = 0; j < n; ++j) {
-            const float r = rewards[j];
-            sum = __fadd_rn(sum, r);
-            d |= r >= 1.0f; p |= r == 0.3f; o |= r == 0.1f;
-        }
-        first_rows[0] += (double)__fdiv_rn(sum, (float)n);
-        first_rows[1] += d ? 1.0 : 0.0;
-        first_rows[2] += p ? 1.0 : 0.0;
-        first_rows[3] += o ? 1.0 : 0.0;
+        first_rows_update(rewards, N, first_rows);
     }
 }
 
 hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
                                 double* first_rows, hipStream_t stream) {
     const int C = reward_event_chunks(E * A);
-    hipLaunchKernelGGL(reward_events_partial_kernel, dim3(C), dim3(EVENT_BLOCK), 0, stream, rewards, E, A, partial);
+    if (C == 1) {
+        hipLaunchKernelGGL(reward_events_partial_kernel, dim3(1), dim3(EVENT_BLOCK), 0, stream, rewards, E, A, partial,
+                           totals, first_rows);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(reward_events_partial_kernel, dim3(C), dim3(EVENT_BLOCK), 0, stream, rewards, E, A, partial,
+                       static_cast<uint64_t*>(nullptr), static_cast<double*>(nullptr));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(reward_events_finish_kernel, dim3(1), dim3(64), 0, stream, rewards, E * A, partial, C, totals,

@@ -133,5 +133,19 @@ class Agent(nn.Module):
         value = self._central(joint_obs) if joint_obs is not None else _linear(self.critic, hidden, False)
         return action, dist.log_prob(action), dist.entropy(), value
 
+    def rollout_step(self, x, logprob_out, value_out):
+        """The rollout half of `get_action_and_value` for the decentralised critic, writing the
+        log-probabilities and the values straight into the given rows of the rollout store
+        (float32 [rows] each) instead of returning fresh tensors that are then copied.  Same
+        numbers as `get_action_and_value`; needs `use_fused_sampling` and runs without autograd."""
+        if self.sampler is None:
+            raise RuntimeError("rollout_step needs use_fused_sampling()")
+        with torch.no_grad():
+            hidden = self._trunk(x)
+            logits = _linear(self.actor, hidden, False)
+            torch.addmm(self.critic.bias, hidden, self.critic.weight.t(), out=value_out.view(-1, 1))
+            actions, _, _ = self.sampler.sample(logits, want_entropy=False, logprob_out=logprob_out)
+        return actions
+
     def get_prob(self, x):
         return Categorical(logits=_linear(self.actor, self._trunk(x), False), validate_args=False)

@@ -23,13 +23,18 @@ class CategoricalSampler:
         self.device = torch.device(device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
 
-    def sample(self, logits: torch.Tensor, want_entropy: bool = True):
+    def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None):
+        """`actions_out` (int64 [rows]) / `logprob_out` (float32 [rows]): contiguous tensors to write
+        into, e.g. a row of the rollout store, instead of fresh ones."""
         if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
             raise ValueError("logits must be a float32 [rows, actions] tensor on the GPU")
         logits = logits.contiguous()
         n, k = logits.shape
-        actions = torch.empty(n, dtype=torch.int64, device=logits.device)
-        logprob = torch.empty(n, dtype=torch.float32, device=logits.device)
+        for t, dt, name in ((actions_out, torch.int64, "actions_out"), (logprob_out, torch.float32, "logprob_out")):
+            if t is not None and (t.dtype != dt or t.shape != (n,) or not t.is_contiguous() or t.device != logits.device):
+                raise ValueError(f"{name} must be a contiguous {dt} tensor of {n} entries on the logits' device")
+        actions = actions_out if actions_out is not None else torch.empty(n, dtype=torch.int64, device=logits.device)
+        logprob = logprob_out if logprob_out is not None else torch.empty(n, dtype=torch.float32, device=logits.device)
         entropy = torch.empty(n, dtype=torch.float32, device=logits.device) if want_entropy else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731

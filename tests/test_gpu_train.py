@@ -30,10 +30,13 @@ def test_training_runs_and_logs(tmp_path, algorithm, layout):
     assert any(n.endswith("_returns_seed_3.csv") for n in files)
 
 
+@pytest.mark.parametrize("fused_sampler", [False, True])
 @pytest.mark.parametrize("graph_rollout", ["off", "on"])
-def test_rollout_buffer_matches_manual_loop(graph_rollout):
-    """The driver's zero-copy observation hand-off (eager, and replayed from hipGraphs) stores
-    exactly what a plain step/copy loop would store, across updates and episode ends."""
+def test_rollout_buffer_matches_manual_loop(graph_rollout, fused_sampler):
+    """The driver's zero-copy hand-offs (eager, and replayed from hipGraphs) store exactly what a
+    plain step/copy loop would store, across updates and episode ends: observations written by
+    the env kernel into the next row and, with the fused sampler, rewards, log-probabilities,
+    values and done flags written into their rows by the kernels that produce them."""
     import types
 
     from marl_amd.agents import MAPPO
@@ -61,9 +64,12 @@ def test_rollout_buffer_matches_manual_loop(graph_rollout):
     vec = make_vector_env(E, env, seed=9, device=dev)
     torch.manual_seed(0)
     net = Agent(vec.single_observation_space, vec.single_action_space, A, E).to(dev)
+    if fused_sampler:
+        net.use_fused_sampling(77)
     buf = Buffer(vec.D, A, E, max_size=T, device=dev)
     args = types.SimpleNamespace(num_steps=T, num_envs=E, num_agents=A, log=False, graph_rollout=graph_rollout)
     agent = Recorder(vec, None, net, buf, None, None, batch_size=E * A * T, num_agents=A, args=args)
+    assert agent.can_act_into() == fused_sampler
     torch.manual_seed(1)
     returns, _ = agent_environment_loop(agent, vec, dev, num_update=updates, args=args)
     assert len(agent.snaps) == updates and len(returns) == updates * T // 10
