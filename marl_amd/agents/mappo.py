@@ -65,15 +65,24 @@ class MAPPO:
                 return self.policy.get_action_and_value(obs, joint_obs=obs.view(1, -1))
             return self.policy.get_action_and_value(obs)
 
-    def act_into(self, obs, step):
+    def act_into(self, obs, step, actions_out):
         """`act` + the learner-side half of `add_to_buffer` for row `step` of the rollout store:
         log-probabilities and values are written into their rows by the kernels that produce them,
-        the actions are stored as float32 like the reference does (buffer.py:12).  Returns the
-        int64 actions for the env.  Decentralised critic with fused sampling only."""
+        the int64 actions into `actions_out` (the env reads them there; the driver converts a
+        whole rollout of them to the store's float32 at once, `store_actions`).  Call `step` of a
+        rollout draws with call number rollout * num_steps + step.  Decentralised critic with
+        fused sampling only."""
         buf = self.buffer
-        actions = self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step])
-        buf.actions_buff[step].copy_(actions)
-        return actions
+        return self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step], actions_out, slot=step)
+
+    def begin_direct_rollouts(self, num_steps):
+        self.policy.sampler.use_slots(num_steps)
+
+    def end_direct_rollout(self, actions_rows):
+        """after the last step of a rollout: the actions as the reference stores them (float32,
+        buffer.py:12) and the call numbers of the next rollout"""
+        self.buffer.actions_buff.copy_(actions_rows)
+        self.policy.sampler.advance_round()
 
     def can_act_into(self):
         return not self.centralised and getattr(self.policy, "sampler", None) is not None

@@ -133,7 +133,7 @@ class Agent(nn.Module):
         value = self._central(joint_obs) if joint_obs is not None else _linear(self.critic, hidden, False)
         return action, dist.log_prob(action), dist.entropy(), value
 
-    def rollout_step(self, x, logprob_out, value_out):
+    def rollout_step(self, x, logprob_out, value_out, actions_out=None, slot=None):
         """The rollout half of `get_action_and_value` for the decentralised critic, writing the
         log-probabilities and the values straight into the given rows of the rollout store
         (float32 [rows] each) instead of returning fresh tensors that are then copied.  Same
@@ -144,7 +144,8 @@ class Agent(nn.Module):
             hidden = self._trunk(x)
             logits = _linear(self.actor, hidden, False)
             torch.addmm(self.critic.bias, hidden, self.critic.weight.t(), out=value_out.view(-1, 1))
-            actions, _, _ = self.sampler.sample(logits, want_entropy=False, logprob_out=logprob_out)
+            actions, _, _ = self.sampler.sample(logits, want_entropy=False, actions_out=actions_out,
+                                                logprob_out=logprob_out, slot=slot)
         return actions
 
     def get_prob(self, x):

@@ -84,26 +84,25 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
 
     # With the decentralised critic and the fused sampler every producer writes straight into the
     # rollout store: the env kernel the next observation and the rewards, the sampler the
-    # log-probabilities, the critic head the values, and the done flag goes to the row after
-    # (five copy launches and two elementwise ones fewer per step, which is a quarter of a
-    # launch-bound step).
-    direct = bool(getattr(agent, "can_act_into", lambda: False)())
-    terminated = torch.empty(N, dtype=torch.bool, device=device)
-    truncated = torch.empty(N, dtype=torch.bool, device=device)
-
-    def done_slot(step):
-        return buf.dones_buff[step] if step < collect_steps else dones
+    # log-probabilities, the critic head the values.  What the store wants in another type (actions
+    # as float32, the done flag as float32 one row on) is kept per step in its native type and
+    # converted once per rollout, and the sampler's call counter moves once per rollout: nine
+    # launches fewer per step, a third of a launch-bound step.
+    direct = bool(getattr(agent, "can_act_into", lambda: False)()) and buf.max_size == collect_steps
+    if direct:
+        act_rows = torch.empty((collect_steps, N), dtype=torch.int64, device=device)
+        term_rows = torch.empty((collect_steps, N), dtype=torch.bool, device=device)
+        trunc_rows = torch.empty((collect_steps, N), dtype=torch.bool, device=device)
+        agent.begin_direct_rollouts(collect_steps)
 
     def one_step(step):
         # every tensor touched here has a fixed address per step index, so the same code can be
         # captured into a graph and replayed
         obs = slot(step)
         if direct:
-            actions = agent.act_into(obs, step)
-            env.step_into(actions, slot(step + 1), buf.rewards_buff[step], terminated, truncated)
+            agent.act_into(obs, step, act_rows[step])
+            env.step_into(act_rows[step], slot(step + 1), buf.rewards_buff[step], term_rows[step], trunc_rows[step])
             stats.add(buf.rewards_buff[step])
-            # row `step` already holds the flag of the step before it; this step's goes one row on
-            torch.logical_or(terminated, truncated, out=done_slot(step + 1))
             buf.ptr = (step + 1) % buf.max_size
             buf.size = min(max(buf.size, step + 1), buf.max_size)
             return
@@ -185,6 +184,13 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 stats.reset()
                 steps_in_episode = 0
                 num_episodes += 1
+        if direct:
+            # row k of the store holds the flag of the step BEFORE it: rows 1.. from this rollout's
+            # steps, row 0 from the previous rollout's last step (copied below, after the update)
+            if collect_steps > 1:
+                torch.logical_or(term_rows[:-1], trunc_rows[:-1], out=buf.dones_buff[1:])
+            torch.logical_or(term_rows[-1], trunc_rows[-1], out=dones)
+            agent.end_direct_rollout(act_rows)
         drain_before_collective()
         agent.update(carry)
         # the stored rows restart at 0: the carried observation (and its done flag) becomes row 0

@@ -22,10 +22,25 @@ class CategoricalSampler:
         self.row_index_base = int(row_index_base)
         self.device = torch.device(device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._slots = None
 
-    def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None):
+    def use_slots(self, calls_per_round: int) -> None:
+        """For a loop that makes the same `calls_per_round` calls round after round (a rollout):
+        call k of a round reads its call number from its own device word, and `advance_round()`
+        moves all of them on at once, so the per-call increment launch goes away.  The numbers
+        are those the single counter would have taken (round * calls_per_round + k)."""
+        if self._slots is None or self._slots.numel() != calls_per_round:
+            base = int(self.counter.item())
+            self._slots = base + torch.arange(calls_per_round, dtype=torch.int64, device=self.device)
+
+    def advance_round(self) -> None:
+        self._slots.add_(self._slots.numel())
+        self.counter.add_(self._slots.numel())
+
+    def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None, slot=None):
         """`actions_out` (int64 [rows]) / `logprob_out` (float32 [rows]): contiguous tensors to write
-        into, e.g. a row of the rollout store, instead of fresh ones."""
+        into, e.g. a row of the rollout store, instead of fresh ones.  `slot`: index of this call
+        within its round (see `use_slots`); without it the single counter is used and advanced."""
         if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
             raise ValueError("logits must be a float32 [rows, actions] tensor on the GPU")
         logits = logits.contiguous()
@@ -38,8 +53,10 @@ class CategoricalSampler:
         entropy = torch.empty(n, dtype=torch.float32, device=logits.device) if want_entropy else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, self.seed, p(self.counter), self.row_index_base,
+        counter = self.counter if slot is None else self._slots[slot]
+        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, self.seed, p(counter), self.row_index_base,
                                                       p(actions), p(logprob), p(entropy), stream),
                    "marl_sample_categorical")
-        self.counter.add_(1)
+        if slot is None:
+            self.counter.add_(1)
         return actions, logprob, entropy
