@@ -158,9 +158,14 @@ size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
 
 /*
  * The sampling half of MAPPO.act (agents/MAPPO.py:58-77 -> model.py:52-56): for every row of
- * d_logits (float32 [num_rows][num_actions], row-major) draw an action from
- * Categorical(logits=row) and report its log-probability and the distribution's entropy.
+ * d_logits (float32, row-major, row_stride floats from one row to the next; 0 = num_actions)
+ * draw an action from Categorical(logits=row[0:num_actions]) and report its log-probability
+ * and the distribution's entropy.
  *   d_actions  int64 [num_rows];  d_logprob, d_entropy  float32 [num_rows] or NULL.
+ *   d_next_column  float32 [num_rows] or NULL: receives row[num_actions] of every row (needs
+ *   row_stride > num_actions).  For callers that compute the critic's value in the same GEMM
+ *   as the logits (model.py:49-61 evaluates actor and critic on the same hidden layer): the
+ *   value comes out contiguous without a strided copy of its own.
  *   seed, d_counter, row_index_base: the uniform of a row comes from a counter RNG keyed by
  *   (seed, *d_counter, row_index_base + row).  d_counter is a uint64 in DEVICE memory (NULL = 0)
  *   that the caller advances between calls (it is read, not written, here: a launch captured
@@ -169,9 +174,9 @@ size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
  * (logits - logsumexp; -sum p * log p); they agree with PyTorch's to the last bits, not bit
  * for bit (another exp / log implementation).
  */
-int marl_sample_categorical(const float *d_logits, int num_rows, int num_actions, uint64_t seed,
+int marl_sample_categorical(const float *d_logits, int num_rows, int num_actions, int row_stride, uint64_t seed,
                             const uint64_t *d_counter, int64_t row_index_base, int64_t *d_actions,
-                            float *d_logprob, float *d_entropy, void *stream);
+                            float *d_logprob, float *d_entropy, float *d_next_column, void *stream);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,7 @@ def lib() -> ctypes.CDLL:
     L.marl_reward_events_workspace_bytes.restype = ctypes.c_size_t
     L.marl_reward_events_workspace_bytes.argtypes = [ci, ci]
     L.marl_sample_categorical.restype = ci
-    L.marl_sample_categorical.argtypes = [vp, ci, ci, ctypes.c_uint64, vp, ctypes.c_int64, vp, vp, vp, vp]
+    L.marl_sample_categorical.argtypes = [vp, ci, ci, ci, ctypes.c_uint64, vp, ctypes.c_int64, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

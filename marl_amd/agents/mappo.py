@@ -78,6 +78,9 @@ class MAPPO:
     def begin_direct_rollouts(self, num_steps):
         self.policy.sampler.use_slots(num_steps)
 
+    def begin_direct_rollout(self):
+        self.policy.refresh_rollout_heads()  # the update changed the parameters
+
     def end_direct_rollout(self, actions_rows):
         """after the last step of a rollout: the actions as the reference stores them (float32,
         buffer.py:12) and the call numbers of the next rollout"""

@@ -39,9 +39,9 @@ hipError_t launch_row_sums(const float* x, int T, int N, double* partial, double
                            hipStream_t stream);
 int row_sum_chunks(int N);
 int reward_event_chunks(int N);
-hipError_t launch_sample_categorical(const float* logits, int N, int K, uint32_t key, const uint64_t* counter,
+hipError_t launch_sample_categorical(const float* logits, int N, int K, int ld, uint32_t key, const uint64_t* counter,
                                      uint64_t row_base, long long* actions, float* logprob, float* entropy,
-                                     hipStream_t stream);
+                                     float* next_col, hipStream_t stream);
 hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
                                 double* first_rows, hipStream_t stream);
 }  // namespace oc
@@ -563,18 +563,23 @@ extern "C" int marl_reward_events(const float* d_rewards, int num_envs, int num_
     return e == hipSuccess ? MARL_OK : fail_hip(e, "reward event kernel launch");
 }
 
-extern "C" int marl_sample_categorical(const float* d_logits, int num_rows, int num_actions, uint64_t seed,
-                                       const uint64_t* d_counter, int64_t row_index_base, int64_t* d_actions,
-                                       float* d_logprob, float* d_entropy, void* stream) {
+extern "C" int marl_sample_categorical(const float* d_logits, int num_rows, int num_actions, int row_stride,
+                                       uint64_t seed, const uint64_t* d_counter, int64_t row_index_base,
+                                       int64_t* d_actions, float* d_logprob, float* d_entropy, float* d_next_column,
+                                       void* stream) {
     if (!d_logits || !d_actions) return fail(MARL_ERR_INVALID, "NULL argument to marl_sample_categorical");
     if (num_rows <= 0 || num_actions <= 0 || num_actions > 64)
         return fail(MARL_ERR_INVALID, "num_rows must be positive and num_actions in [1, 64]");
+    if (row_stride == 0) row_stride = num_actions;
+    if (row_stride < num_actions) return fail(MARL_ERR_INVALID, "row_stride is smaller than num_actions");
+    if (d_next_column && row_stride <= num_actions)
+        return fail(MARL_ERR_INVALID, "d_next_column needs rows of more than num_actions floats (row_stride)");
     if (((uintptr_t)d_actions & 7u) != 0 || ((uintptr_t)d_counter & 7u) != 0 || ((uintptr_t)d_logits & 3u) != 0)
         return fail(MARL_ERR_INVALID, "d_actions and d_counter must be 8-byte aligned, d_logits 4-byte aligned");
     uint32_t k = mix32_host((uint32_t)seed + 0x9E3779B9u);
     k = mix32_host(k ^ (uint32_t)(seed >> 32));
-    hipError_t e = launch_sample_categorical(d_logits, num_rows, num_actions, k, d_counter, (uint64_t)row_index_base,
-                                             reinterpret_cast<long long*>(d_actions), d_logprob, d_entropy,
-                                             reinterpret_cast<hipStream_t>(stream));
+    hipError_t e = launch_sample_categorical(d_logits, num_rows, num_actions, row_stride, k, d_counter,
+                                             (uint64_t)row_index_base, reinterpret_cast<long long*>(d_actions), d_logprob,
+                                             d_entropy, d_next_column, reinterpret_cast<hipStream_t>(stream));
     return e == hipSuccess ? MARL_OK : fail_hip(e, "sampling kernel launch");
 }

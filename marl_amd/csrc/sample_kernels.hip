@@ -7,6 +7,8 @@
 //   entropy  = - sum_k (e_k / S) * (l_k - lse)
 // u comes from a counter RNG keyed by (seed, call counter, global row), so a rollout is
 // reproducible and a shard of a larger job draws what the whole job would have drawn.
+// Rows may be wider than K (row stride `ld`): a caller that computes the critic's value in the
+// same GEMM as the logits (one more output column) gets that column copied out alongside.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,12 +22,12 @@ __device__ __forceinline__ uint32_t smix32(uint32_t x) {
 }
 
 __global__ void __launch_bounds__(256)
-sample_categorical_kernel(const float* __restrict__ logits, int N, int K, uint32_t key, const uint64_t* __restrict__ counter,
-                          uint64_t row_base, long long* __restrict__ actions, float* __restrict__ logprob,
-                          float* __restrict__ entropy) {
+sample_categorical_kernel(const float* __restrict__ logits, int N, int K, int ld, uint32_t key,
+                          const uint64_t* __restrict__ counter, uint64_t row_base, long long* __restrict__ actions,
+                          float* __restrict__ logprob, float* __restrict__ entropy, float* __restrict__ next_col) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float* l = logits + (size_t)n * K;
+    const float* l = logits + (size_t)n * ld;
     float m = l[0];
     for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
     float S = 0.0f;
@@ -53,13 +55,14 @@ sample_categorical_kernel(const float* __restrict__ logits, int N, int K, uint32
     actions[n] = a;
     if (logprob) logprob[n] = __fsub_rn(l[a], lse);
     if (entropy) entropy[n] = ent;
+    if (next_col) next_col[n] = l[K];
 }
 
-hipError_t launch_sample_categorical(const float* logits, int N, int K, uint32_t key, const uint64_t* counter,
+hipError_t launch_sample_categorical(const float* logits, int N, int K, int ld, uint32_t key, const uint64_t* counter,
                                      uint64_t row_base, long long* actions, float* logprob, float* entropy,
-                                     hipStream_t stream) {
-    hipLaunchKernelGGL(sample_categorical_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, logits, N, K, key, counter,
-                       row_base, actions, logprob, entropy);
+                                     float* next_col, hipStream_t stream) {
+    hipLaunchKernelGGL(sample_categorical_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, logits, N, K, ld, key, counter,
+                       row_base, actions, logprob, entropy, next_col);
     return hipGetLastError();
 }
 

@@ -154,6 +154,8 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             pass
     for update_index in rng:
         step = 0
+        if direct:
+            agent.begin_direct_rollout()
         while step < collect_steps:
             count = min(collect_steps - step, max_steps - steps_in_episode)
             run_segment(step, count, warm=update_index > 0)  # the first rollout runs eagerly (lazy library set-up)

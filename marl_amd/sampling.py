@@ -37,15 +37,23 @@ class CategoricalSampler:
         self._slots.add_(self._slots.numel())
         self.counter.add_(self._slots.numel())
 
-    def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None, slot=None):
+    def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None, slot=None,
+               num_actions=None, next_column_out=None):
         """`actions_out` (int64 [rows]) / `logprob_out` (float32 [rows]): contiguous tensors to write
         into, e.g. a row of the rollout store, instead of fresh ones.  `slot`: index of this call
-        within its round (see `use_slots`); without it the single counter is used and advanced."""
+        within its round (see `use_slots`); without it the single counter is used and advanced.
+        `num_actions`: the first so many columns of `logits` are the logits (default: all);
+        `next_column_out` (float32 [rows]) then receives the column after them, e.g. the critic's
+        value when both heads come out of one GEMM."""
         if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
             raise ValueError("logits must be a float32 [rows, actions] tensor on the GPU")
         logits = logits.contiguous()
-        n, k = logits.shape
-        for t, dt, name in ((actions_out, torch.int64, "actions_out"), (logprob_out, torch.float32, "logprob_out")):
+        n, ld = logits.shape
+        k = ld if num_actions is None else int(num_actions)
+        if not 0 < k <= ld or (next_column_out is not None and k >= ld):
+            raise ValueError(f"num_actions={k} does not fit rows of {ld} columns (next_column_out needs one more)")
+        for t, dt, name in ((actions_out, torch.int64, "actions_out"), (logprob_out, torch.float32, "logprob_out"),
+                            (next_column_out, torch.float32, "next_column_out")):
             if t is not None and (t.dtype != dt or t.shape != (n,) or not t.is_contiguous() or t.device != logits.device):
                 raise ValueError(f"{name} must be a contiguous {dt} tensor of {n} entries on the logits' device")
         actions = actions_out if actions_out is not None else torch.empty(n, dtype=torch.int64, device=logits.device)
@@ -54,8 +62,8 @@ class CategoricalSampler:
         stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
         counter = self.counter if slot is None else self._slots[slot]
-        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, self.seed, p(counter), self.row_index_base,
-                                                      p(actions), p(logprob), p(entropy), stream),
+        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, ld, self.seed, p(counter), self.row_index_base,
+                                                      p(actions), p(logprob), p(entropy), p(next_column_out), stream),
                    "marl_sample_categorical")
         if slot is None:
             self.counter.add_(1)

@@ -47,3 +47,32 @@ def test_frequencies_follow_the_distribution():
     first, _, _ = s.sample(t[:1000])
     second, _, _ = s.sample(t[:1000])
     assert not torch.equal(first, second)
+
+
+def test_wide_rows_slots_and_caller_buffers():
+    """Rows wider than the action count (the critic's value riding in the next column), results
+    written into caller tensors, and per-call counter slots: same draws as the plain call."""
+    from marl_amd.sampling import CategoricalSampler
+
+    torch.manual_seed(3)
+    n, k = 3000, 7
+    wide = torch.randn(n, k + 1, device="cuda") * 2
+    plain = CategoricalSampler(seed=5, row_index_base=40)
+    slotted = CategoricalSampler(seed=5, row_index_base=40)
+    slotted.use_slots(4)
+    for rnd in range(2):
+        for call in range(4):
+            a0, lp0, _ = plain.sample(wide[:, :k].contiguous())
+            a1 = torch.empty(n, dtype=torch.int64, device="cuda")
+            lp1 = torch.empty(n, device="cuda")
+            v1 = torch.empty(n, device="cuda")
+            out = slotted.sample(wide, want_entropy=False, actions_out=a1, logprob_out=lp1, slot=call, num_actions=k,
+                                 next_column_out=v1)
+            assert out[0] is a1 and out[1] is lp1 and out[2] is None
+            assert torch.equal(a0, a1) and torch.equal(lp0, lp1) and torch.equal(v1, wide[:, k])
+        slotted.advance_round()
+    assert int(plain.counter) == int(slotted.counter) == 8
+    with pytest.raises(ValueError):
+        slotted.sample(wide[:, :k].contiguous(), next_column_out=torch.empty(n, device="cuda"))
+    with pytest.raises(ValueError):
+        slotted.sample(wide, actions_out=torch.empty(n, dtype=torch.int32, device="cuda"))
