@@ -178,6 +178,30 @@ int marl_sample_categorical(const float *d_logits, int num_rows, int num_actions
                             const uint64_t *d_counter, int64_t row_index_base, int64_t *d_actions,
                             float *d_logprob, float *d_entropy, float *d_next_column, void *stream);
 
+/*
+ * Loss and head gradients of one PPO minibatch, agents/MAPPO.py:167-200 (decentralised critic;
+ * value loss agents/MAPPO.py:243-248, distribution model.py:52-56):
+ *   loss = mean(max(-A r, -A clamp(r, 1-clip, 1+clip))) - entropy_coef mean(H) + value_coef mean(0.5 (v - target)^2)
+ * with r = exp(log_prob(action) - old_log_prob), H the entropy of Categorical(logits=row).
+ * Sample n takes its logits from row n of d_logits (float32, row_stride floats per row, 0 =
+ * num_actions) and its value from d_values[n]; action (stored as float32 like buffer.py:12),
+ * old log-probability, advantage and value target come from entry d_index[n] of the rollout
+ * store's flat arrays (d_index NULL: entry n).
+ *   d_grad_logits float32 [num_samples][num_actions], d_grad_values float32 [num_samples]:
+ *                 d loss / d logits and d loss / d values (the loss is a mean, so no second pass)
+ *   d_stats       double[7]: loss, then the means the learner logs (MAPPO.py:211-218): value loss,
+ *                 policy loss, entropy, approx_kl = mean((r - 1) - log r), old_approx_kl =
+ *                 mean(-log r), clip fraction = mean(|r - 1| > clip)
+ *   d_workspace   marl_ppo_loss_workspace_bytes(num_samples) bytes, 8-byte aligned.
+ * Agrees with the autograd evaluation of the same formulas to float32 rounding.
+ */
+int marl_ppo_loss(const float *d_logits, int num_samples, int num_actions, int row_stride, const float *d_values,
+                  const int64_t *d_index, const float *d_actions, const float *d_old_logprob,
+                  const float *d_advantages, const float *d_value_target, double clip, double entropy_coef,
+                  double value_coef, float *d_grad_logits, float *d_grad_values, double *d_stats, void *d_workspace,
+                  void *stream);
+size_t marl_ppo_loss_workspace_bytes(int num_samples);
+
 #ifdef __cplusplus
 }
 #endif

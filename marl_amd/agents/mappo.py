@@ -29,7 +29,7 @@ class MAPPO:
     def __init__(self, env, optimzer, policy, buffer, single_agent_obs, single_agent_action, batch_size=1,
                  num_mini_batches=4, num_agents=4, ppo_epoch=10, clip_param=0.2, value_loss_coef=0.5,
                  entropy_coef=0.01, max_grad_norm=0.5, gamma=0.99, lam=0.95, save_path=None, log_dir=None,
-                 log=False, args=None, shuffle="device", writer=None, graph_update="off"):
+                 log=False, args=None, shuffle="device", writer=None, graph_update="off", fused_loss=True):
         self.env, self.optimizer, self.policy, self.buffer = env, optimzer, policy, buffer
         self.num_agents = num_agents
         self.single_agent_obs, self.single_agent_action = single_agent_obs, single_agent_action
@@ -52,6 +52,10 @@ class MAPPO:
         self._graph_update = (graph_update == "on" or (graph_update == "auto" and small)) \
             and dist_utils.world_size() == 1 and self.device.type == "cuda" and optimzer is not None
         self._g = None
+        # loss + head gradients from one HIP pass (marl_amd.ppo_loss) instead of ~70 autograd ops:
+        # the decentralised loss on the GPU only (CMAPPO's value loss has another form)
+        self._fused_loss = bool(fused_loss) and self.device.type == "cuda" and not self.centralised \
+            and type(self).compute_value_loss is MAPPO.compute_value_loss
         if self._graph_update:
             for group in optimzer.param_groups:  # the step counter must live on the device to be captured
                 group["capturable"] = True
@@ -110,6 +114,18 @@ class MAPPO:
     # ------------------------------------------------------------------ update
     def _minibatch_step(self, mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target):
         """agents/MAPPO.py:167-209 for one minibatch; returns the six logged statistics."""
+        if self._fused_loss:
+            from ..ppo_loss import ppo_loss
+
+            logits, newvalue = self.policy.logits_and_value(b_obs[mb])
+            loss, stats = ppo_loss(logits, newvalue, mb, b_actions_f, b_logprobs, b_advantages, b_value_target,
+                                   self.clip_param, self.entropy_coef, self.value_loss_coef)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self._reducer()
+            torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            return stats[1:]
         _, newlogprob, entropy, newvalue = self.policy.get_action_and_value(b_obs[mb], b_actions_f[mb].long())
         logratio = newlogprob - b_logprobs[mb]
         ratio = logratio.exp()

@@ -42,6 +42,11 @@ int reward_event_chunks(int N);
 hipError_t launch_sample_categorical(const float* logits, int N, int K, int ld, uint32_t key, const uint64_t* counter,
                                      uint64_t row_base, long long* actions, float* logprob, float* entropy,
                                      float* next_col, hipStream_t stream);
+int ppo_loss_chunks(int M);
+hipError_t launch_ppo_loss(const float* logits, int M, int K, int ld, const float* values, const long long* index,
+                           const float* actions_f, const float* old_logprob, const float* advantages,
+                           const float* value_target, float clip, float entropy_coef, float value_coef,
+                           float* grad_logits, float* grad_values, double* stats, double* partial, hipStream_t stream);
 hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
                                 double* first_rows, hipStream_t stream);
 }  // namespace oc
@@ -582,4 +587,31 @@ extern "C" int marl_sample_categorical(const float* d_logits, int num_rows, int 
                                              (uint64_t)row_index_base, reinterpret_cast<long long*>(d_actions), d_logprob,
                                              d_entropy, d_next_column, reinterpret_cast<hipStream_t>(stream));
     return e == hipSuccess ? MARL_OK : fail_hip(e, "sampling kernel launch");
+}
+
+extern "C" size_t marl_ppo_loss_workspace_bytes(int num_samples) {
+    if (num_samples <= 0) return 0;
+    return (size_t)ppo_loss_chunks(num_samples) * 6 * sizeof(double);
+}
+
+extern "C" int marl_ppo_loss(const float* d_logits, int num_samples, int num_actions, int row_stride,
+                             const float* d_values, const int64_t* d_index, const float* d_actions,
+                             const float* d_old_logprob, const float* d_advantages, const float* d_value_target,
+                             double clip, double entropy_coef, double value_coef, float* d_grad_logits,
+                             float* d_grad_values, double* d_stats, void* d_workspace, void* stream) {
+    if (!d_logits || !d_values || !d_actions || !d_old_logprob || !d_advantages || !d_value_target || !d_grad_logits ||
+        !d_grad_values || !d_stats || !d_workspace)
+        return fail(MARL_ERR_INVALID, "NULL argument to marl_ppo_loss");
+    if (num_samples <= 0 || num_actions < 2 || num_actions > 8)
+        return fail(MARL_ERR_INVALID, "num_samples must be positive and num_actions in [2, 8]");
+    if (row_stride == 0) row_stride = num_actions;
+    if (row_stride < num_actions) return fail(MARL_ERR_INVALID, "row_stride is smaller than num_actions");
+    if (((uintptr_t)d_stats & 7u) != 0 || ((uintptr_t)d_workspace & 7u) != 0 || ((uintptr_t)d_index & 7u) != 0)
+        return fail(MARL_ERR_INVALID, "d_stats, d_workspace and d_index must be 8-byte aligned");
+    hipError_t e = launch_ppo_loss(d_logits, num_samples, num_actions, row_stride, d_values,
+                                   reinterpret_cast<const long long*>(d_index), d_actions, d_old_logprob, d_advantages,
+                                   d_value_target, (float)clip, (float)entropy_coef, (float)value_coef, d_grad_logits,
+                                   d_grad_values, d_stats, reinterpret_cast<double*>(d_workspace),
+                                   reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "PPO loss kernel launch");
 }

@@ -163,5 +163,10 @@ class Agent(nn.Module):
                                                 slot=slot, num_actions=self.actor.out_features, next_column_out=value_out)
         return actions
 
+    def logits_and_value(self, x):
+        """both heads on the shared trunk (model.py:49-61 without the distribution object)"""
+        hidden = self._trunk(x)
+        return _linear(self.actor, hidden, False), _linear(self.critic, hidden, False)
+
     def get_prob(self, x):
         return Categorical(logits=_linear(self.actor, self._trunk(x), False), validate_args=False)

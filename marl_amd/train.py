@@ -69,6 +69,8 @@ def build_parser():
                    help="rollout action sampling: one HIP launch with a counter RNG, or torch.distributions")
     p.add_argument("--graph-update", choices=["auto", "on", "off"], default="auto",
                    help="replay the PPO minibatch step from a hipGraph (auto: single rank and minibatches of at most 65,536 samples)")
+    p.add_argument("--fused-loss", choices=["on", "off"], default="on",
+                   help="decentralised MAPPO on the GPU: loss and head gradients from one HIP pass instead of autograd's small ops")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
                    help="replay rollout steps from hipGraphs (auto: single rank and at most 16,384 rows per launch)")
     return p
@@ -127,7 +129,8 @@ def main(argv=None):
                 value_loss_coef=args.value_loss_coef, entropy_coef=args.entropy_coef,
                 max_grad_norm=args.max_grad_norm, gamma=args.gamma, lam=args.lam, save_path=args.save_path,
                 log_dir=log_dir, num_agents=args.num_agents, log=args.log and rank == 0, args=args,
-                shuffle=args.shuffle, writer=writer, graph_update=args.graph_update)
+                shuffle=args.shuffle, writer=writer, graph_update=args.graph_update,
+                fused_loss=args.fused_loss == "on")
     num_updates = args.total_steps // batch_size  # main.py:302
 
     t0 = time.time()
