@@ -69,6 +69,8 @@ def build_parser():
                    help="rollout action sampling: one HIP launch with a counter RNG, or torch.distributions")
     p.add_argument("--graph-update", choices=["auto", "on", "off"], default="auto",
                    help="replay the PPO minibatch step from a hipGraph (auto: single rank and minibatches of at most 65,536 samples)")
+    p.add_argument("--adam", choices=["fused", "foreach"], default="fused",
+                   help="Adam step as one multi-tensor launch (GPU only) or PyTorch's default per-operation launches")
     p.add_argument("--fused-loss", choices=["on", "off"], default="on",
                    help="decentralised MAPPO on the GPU: loss and head gradients from one HIP pass instead of autograd's small ops")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
@@ -119,7 +121,10 @@ def main(argv=None):
     dist_utils.broadcast_parameters(net)
     if args.sampler == "fused":
         net.use_fused_sampling(args.seed, row_index_base=rank * args.num_envs * args.num_agents)
-    optimizer = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.95))  # main.py:294
+    # main.py:294.  fused: the whole Adam step is one multi-tensor launch instead of seventeen
+    # (same arithmetic; a minibatch step at the reference's batch sizes is launch-bound)
+    optimizer = torch.optim.Adam(net.parameters(), lr=args.lr, betas=(0.9, 0.95),
+                                 fused=device.type == "cuda" and args.adam == "fused")
     buffer = Buffer(single_obs_dim[0], env.config["num_agents"], args.num_envs, max_size=args.num_steps, device=device)
     # main.py:291,303: the centralised learner is reached only through --algorithm cmappo
     cls = CMAPPO if args.algorithm == "cmappo" else MAPPO
