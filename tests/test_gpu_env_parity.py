@@ -224,18 +224,29 @@ def test_import_state_reproduces_reference_fixture():
     np.testing.assert_array_equal(obs[0:1], gold)
 
 
-def test_full_size_properties():
-    """65,536 envs: sizes the oracle cannot follow quickly are checked through invariants:
-    shards reproduce the whole job, and featurize(state) equals the observation step returned."""
+@pytest.mark.parametrize("layout,A,feature,E", [
+    ("overcooked_cramped_room_v0", 2, "global_obs", 65536),       # the headline workload
+    ("overcooked_coordination_ring_v0", 4, "local_obs", 65536),   # four agents: the env's lanes share the step
+    ("overcooked_counter_circuit_v0", 2, "global_obs", 131072),   # one GPU's share of the 1M-env job
+])
+def test_full_size_properties(oracle_mod, layout, A, feature, E):
+    """The benchmark sizes: what the oracle cannot follow quickly is checked through invariants
+    (shards reproduce the whole job; featurize(state) equals the observation step returned;
+    agents of an env stand on distinct cells), and a slice of the job (first and last 32 envs)
+    against the oracle step by step."""
     from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
 
-    rows = get_layout("overcooked_cramped_room_v0")
-    E, A = 65536, 2
-    whole = BatchedOvercookedVecEnv(rows, A, "global_obs", E, seed=11, env_index_base=0)
-    half = BatchedOvercookedVecEnv(rows, A, "global_obs", E // 2, seed=11, env_index_base=E // 2)
+    rows = get_layout(layout)
+    S = 32
+    whole = BatchedOvercookedVecEnv(rows, A, feature, E, seed=11, env_index_base=0)
+    half = BatchedOvercookedVecEnv(rows, A, feature, E // 2, seed=11, env_index_base=E // 2)
+    head = oracle_mod.OracleVecEnv(rows, A, feature, num_envs=S, seed=11, env_index_base=0)
+    tail = oracle_mod.OracleVecEnv(rows, A, feature, num_envs=S, seed=11, env_index_base=E - S)
     ow, _ = whole.reset()
     oh, _ = half.reset()
     assert torch.equal(ow[OBS_KEY][E // 2 * A:], oh[OBS_KEY])
+    np.testing.assert_array_equal(ow[OBS_KEY][:S * A].cpu().numpy(), head.reset())
+    np.testing.assert_array_equal(ow[OBS_KEY][-S * A:].cpu().numpy(), tail.reset())
     g = torch.Generator(device="cpu").manual_seed(0)
     for t in range(40):
         act = torch.randint(0, 7, (E * A,), generator=g)
@@ -243,10 +254,19 @@ def test_full_size_properties():
         oh, rh, _, _, _ = half.step(act[E // 2 * A:])
         assert torch.equal(ow[OBS_KEY][E // 2 * A:], oh[OBS_KEY]), f"shard diverged at step {t}"
         assert torch.equal(rw[E // 2 * A:], rh)
+        o_head, r_head, _, _ = head.step(act[:S * A].numpy())
+        o_tail, r_tail, _, _ = tail.step(act[-S * A:].numpy())
+        np.testing.assert_array_equal(ow[OBS_KEY][:S * A].cpu().numpy(), o_head, err_msg=f"step {t}")
+        np.testing.assert_array_equal(ow[OBS_KEY][-S * A:].cpu().numpy(), o_tail, err_msg=f"step {t}")
+        np.testing.assert_array_equal(rw[:S * A].cpu().numpy(), r_head)
+        np.testing.assert_array_equal(rw[-S * A:].cpu().numpy(), r_tail)
     assert torch.equal(whole.featurize(), ow[OBS_KEY])
     # observations are small integers: nothing outside what int8 staging can hold
     assert ow[OBS_KEY].abs().max().item() <= 30
     assert torch.equal(ow[OBS_KEY], ow[OBS_KEY].round())
+    cells = torch.from_numpy(whole.export_state()["agents"][:, :, 0] * 64 + whole.export_state()["agents"][:, :, 1])
+    srt = cells.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "two agents of an env share a cell"
 
 
 def test_store_policy_does_not_change_rows(monkeypatch):
