@@ -199,7 +199,7 @@ def main():
                        "launch": "hipGraph of 32 steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_agent_step": B, "kernel": "env_kernel<2,global,1> (step+featurize)",
+                         "bytes_per_agent_step": B, "kernel": f"env_kernel<{A} agents, {args.feature}> (step+featurize)",
                          "us_per_launch": launch_s * 1e6},
         }
         if policy is not None:
