@@ -103,19 +103,23 @@ ppo_loss_partial_kernel(const float* __restrict__ logits, int M, int ld, const f
     }
 }
 
-// stats[0] = loss; stats[1..6] = means of the six statistics, in the order the learner logs them
-__global__ void ppo_loss_finish_kernel(const double* __restrict__ partial, int C, int M, float entropy_coef,
-                                       float value_coef, double* __restrict__ stats) {
+// stats[0] = loss; stats[1..6] = means of the six statistics, in the order the learner logs them.
+// One wave per statistic: lanes stride over the chunk sums, then a shuffle reduction.
+__global__ void __launch_bounds__(64 * PPO_STATS)
+ppo_loss_finish_kernel(const double* __restrict__ partial, int C, int M, float entropy_coef, float value_coef,
+                       double* __restrict__ stats) {
     __shared__ double mean[PPO_STATS];
-    const int k = threadIdx.x;
-    if (k < PPO_STATS) {
-        double s = 0;
-        for (int c = 0; c < C; ++c) s += partial[(size_t)c * PPO_STATS + k];
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s = 0;
+    for (int c = lane; c < C; c += 64) s += partial[(size_t)c * PPO_STATS + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
         mean[k] = s / (double)M;
         stats[1 + k] = mean[k];
     }
     __syncthreads();
-    if (k == 0) stats[0] = mean[1] - (double)entropy_coef * mean[2] + (double)value_coef * mean[0];
+    if (threadIdx.x == 0) stats[0] = mean[1] - (double)entropy_coef * mean[2] + (double)value_coef * mean[0];
 }
 
 hipError_t launch_ppo_loss(const float* logits, int M, int K, int ld, const float* values, const long long* index,
@@ -136,7 +140,7 @@ hipError_t launch_ppo_loss(const float* logits, int M, int K, int ld, const floa
 #undef OC_PPO_CASE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, stream, partial, C, M, entropy_coef, value_coef, stats);
+    hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64 * PPO_STATS), 0, stream, partial, C, M, entropy_coef, value_coef, stats);
     return hipGetLastError();
 }
 
