@@ -135,6 +135,17 @@ __device__ __forceinline__ uint32_t pot_class(uint32_t pots, uint32_t p) {
     return c == (uint32_t)POT_CAPACITY ? full : filling;
 }
 
+// One cooking tick for all pots at once (a byte per pot: count in bits 0-1, timer in bits 2-6;
+// bytes of pots the layout does not have are zero and stay zero): a full pot (count 3) whose
+// timer is above zero loses one timer step.
+__device__ __forceinline__ uint32_t tick_pots(uint32_t pots) {
+    static_assert(POT_CAPACITY == 3, "full means both count bits set");
+    const uint32_t full = pots & (pots >> 1) & 0x01010101u;
+    const uint32_t timer = (pots >> 2) & 0x1F1F1F1Fu;
+    const uint32_t running = ((timer + 0x1F1F1F1Fu) >> 5) & 0x01010101u;  // timer + 31 reaches 32 unless it is 0
+    return pots - ((full & running) << 2);
+}
+
 // pot condition as the decision tables see it
 __device__ __forceinline__ uint32_t pot_state(uint32_t pots, uint32_t p) {
     const uint32_t c = pot_count(pots, p), t = pot_timer(pots, p);
@@ -274,10 +285,7 @@ __device__ __forceinline__ uint32_t step_env(EnvState<A, NIW>& s, const Lds& T, 
 
     s.t += 1;
     // pots that are full keep cooking
-    for (int p = 0; p < P.NP; ++p) {
-        const bool cooking = pot_count(s.pots, p) == (uint32_t)POT_CAPACITY && pot_timer(s.pots, p) > 0;
-        s.pots -= cooking ? (4u << (8u * p)) : 0u;
-    }
+    s.pots = tick_pots(s.pots);
 
     // ---- movement ----
     uint32_t want[A];
@@ -463,10 +471,7 @@ __device__ __forceinline__ uint32_t step_env_quad(EnvState<A, NIW>& s, const Lds
 
     s.t += 1;
     // pots that are full keep cooking
-    for (int p = 0; p < P.NP; ++p) {
-        const bool cooking = pot_count(s.pots, p) == (uint32_t)POT_CAPACITY && pot_timer(s.pots, p) > 0;
-        s.pots -= cooking ? (4u << (8u * p)) : 0u;
-    }
+    s.pots = tick_pots(s.pots);
 
     // ---- movement: my own turn and target, then everybody's ----
     uint32_t want[A];
