@@ -76,17 +76,18 @@ reward_events_partial_kernel(const float* __restrict__ rewards, int E, int A, ui
     }
 }
 
-// pass 2: lanes 0-3 add the chunk sums to the running totals; lane 4 does the first-rows part
-__global__ void reward_events_finish_kernel(const float* __restrict__ rewards, int N, const uint64_t* __restrict__ partial,
-                                            int C, uint64_t* __restrict__ totals, double* __restrict__ first_rows) {
-    const int k = threadIdx.x;
-    if (k < 4) {
-        uint64_t s = 0;
-        for (int c = 0; c < C; ++c) s += partial[(size_t)c * 4 + k];
-        totals[k] += s;
-    } else if (k == 4 && first_rows) {
-        first_rows_update(rewards, N, first_rows);
-    }
+// pass 2: wave k (of four) adds the chunk sums of total k to the running totals; the last lane of
+// the block does the first-rows part
+__global__ void __launch_bounds__(256)
+reward_events_finish_kernel(const float* __restrict__ rewards, int N, const uint64_t* __restrict__ partial, int C,
+                            uint64_t* __restrict__ totals, double* __restrict__ first_rows) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t s = 0;
+    for (int c = lane; c < C; c += 64) s += partial[(size_t)c * 4 + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) totals[k] += s;
+    if (threadIdx.x == 255 && first_rows) first_rows_update(rewards, N, first_rows);
 }
 
 hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
@@ -101,7 +102,7 @@ hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* pa
                        static_cast<uint64_t*>(nullptr), static_cast<double*>(nullptr));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(reward_events_finish_kernel, dim3(1), dim3(64), 0, stream, rewards, E * A, partial, C, totals,
+    hipLaunchKernelGGL(reward_events_finish_kernel, dim3(1), dim3(256), 0, stream, rewards, E * A, partial, C, totals,
                        first_rows);
     return hipGetLastError();
 }
