@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--obs-ring", type=int, default=2,
+                    help="observation buffers the steps cycle through (2: the next step overwrites the rows the consumer "
+                         "has just read, they never have to leave the last-level cache; 128: every step's rows are kept "
+                         "like in a rollout store and drain to HBM)")
     ap.add_argument("--mode", choices=["random", "policy"], default="random",
                     help="random: pre-generated uniform actions (headline); policy: actions sampled from the "
                          "reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm) every step")
@@ -106,7 +110,8 @@ def main():
     R = 32  # distinct pre-generated action batches, cycled
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     actions = torch.randint(0, 7, (R, N), dtype=torch.int64, device=dev, generator=gen)
-    obs = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(2)]
+    RING = max(2, args.obs_ring)
+    obs = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(RING)]
     rew = torch.empty(N, dtype=torch.float32, device=dev)
     term = torch.empty(N, dtype=torch.bool, device=dev)
     trunc = torch.empty(N, dtype=torch.bool, device=dev)
@@ -123,11 +128,11 @@ def main():
 
     def eager(i):
         if policy is None:
-            env.step_into(actions[i % R], obs[i % 2], rew, term, trunc)
+            env.step_into(actions[i % R], obs[i % RING], rew, term, trunc)
         else:
             with torch.no_grad():
-                act, _, _, _ = policy.get_action_and_value(obs[(i + 1) % 2])
-            env.step_into(act, obs[i % 2], rew, term, trunc)
+                act, _, _, _ = policy.get_action_and_value(obs[(i - 1) % RING])
+            env.step_into(act, obs[i % RING], rew, term, trunc)
 
     for i in range(args.warmup):
         eager(i)

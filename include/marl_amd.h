@@ -99,6 +99,19 @@ int marl_env_step(marl_env_t *env, void *d_state, const void *d_actions, int act
                   float *d_obs, float *d_rewards, uint8_t *d_terminated, uint8_t *d_truncated,
                   const uint8_t *d_prio_override, void *stream);
 
+/*
+ * num_steps consecutive env.step calls (agent_environment.py:50) in one launch, for callers that
+ * know the actions of all of them up front (random-action rollouts, replaying a recorded action
+ * sequence): step k reads d_actions[k][N] and writes d_obs[k][N][D], d_rewards[k][N],
+ * d_terminated[k][N], d_truncated[k][N] (d_prio_override[k][N] if given), N = num_envs * num_agents;
+ * results are those of num_steps marl_env_step calls, bit for bit.  The env stays in registers
+ * between steps and the simulation of a step overlaps the previous step's row stores.
+ * N * D must be a multiple of 4 when num_steps > 1 (each step's rows start 16-byte aligned).
+ */
+int marl_env_step_many(marl_env_t *env, void *d_state, const void *d_actions, int action_elem_size, int num_steps,
+                       float *d_obs, float *d_rewards, uint8_t *d_terminated, uint8_t *d_truncated,
+                       const uint8_t *d_prio_override, void *stream);
+
 /* feature_space.generate over the stored state (overcooked_features.py:107-121) */
 int marl_env_featurize(marl_env_t *env, void *d_state, float *d_obs, void *stream);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "libmarl_amd.so
 EXPORTS = (
     "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_set_auto_reset", "marl_env_obs_dim", "marl_env_num_rows",
     "marl_env_num_pots", "marl_env_grid_cells", "marl_env_state_words", "marl_env_state_bytes",
-    "marl_env_reset", "marl_env_step", "marl_env_featurize", "marl_env_export_state",
+    "marl_env_reset", "marl_env_step", "marl_env_step_many", "marl_env_featurize", "marl_env_export_state",
     "marl_env_import_state", "marl_gae", "marl_gae_workspace_bytes", "marl_row_sums",
     "marl_reward_events", "marl_reward_events_workspace_bytes", "marl_sample_categorical",
     "marl_ppo_loss", "marl_ppo_loss_workspace_bytes",
@@ -58,6 +58,8 @@ def lib() -> ctypes.CDLL:
     L.marl_env_step.restype = ci
     L.marl_env_step.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     L.marl_env_featurize.restype = ci
+    L.marl_env_step_many.restype = ci
+    L.marl_env_step_many.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]
     L.marl_env_featurize.argtypes = [vp, vp, vp, vp]
     L.marl_env_export_state.restype = ci
     L.marl_env_export_state.argtypes = [vp, vp, vp, vp, vp, vp, vp]

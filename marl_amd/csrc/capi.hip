@@ -384,7 +384,7 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     int rc = build_tables(env, layout_rows, height, dist_metric);
     if (rc != MARL_OK) { delete env; return rc; }
     EnvParams& P = env->P;
-    P.E = num_envs; P.max_steps = max_steps; P.auto_reset = 1;
+    P.E = num_envs; P.max_steps = max_steps; P.auto_reset = 1; P.nsteps = 1;
     {
         // MARL_AMD_STREAM_NT=0/1 forces the choice (tuning aid)
         const size_t obs_bytes = (size_t)num_envs * num_agents * env->D * sizeof(float);
@@ -434,7 +434,7 @@ extern "C" size_t marl_env_state_bytes(const marl_env_t* env) {
 
 static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, int act_size, const uint8_t* prio,
                           const uint8_t* spawn_ov, const uint8_t* dir_ov, float* d_obs, float* d_rewards,
-                          uint8_t* d_term, uint8_t* d_trunc, int mode, void* stream) {
+                          uint8_t* d_term, uint8_t* d_trunc, int mode, void* stream, int nsteps = 1) {
     if (!env) return fail(MARL_ERR_INVALID, "env is NULL");
     if (!d_state) return fail(MARL_ERR_INVALID, "d_state is NULL");
     if (!d_obs) return fail(MARL_ERR_INVALID, "d_obs is NULL");
@@ -448,11 +448,19 @@ static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, i
         return fail(MARL_ERR_INVALID, "the env was created on HIP device " + std::to_string(env->device) +
                                           " but device " + std::to_string(dev) + " is current");
     uint32_t* st = reinterpret_cast<uint32_t*>(d_state);
+    EnvParams P = env->P;
+    P.nsteps = nsteps;
+    if (nsteps > 1) {
+        // the cache policy follows what the launch writes: all steps' rows
+        const char* v = getenv("MARL_AMD_STREAM_NT");
+        const size_t obs_bytes = (size_t)nsteps * (size_t)P.E * env->A * env->D * sizeof(float);
+        P.stream_nt = v ? (atoi(v) != 0) : (obs_bytes > STREAM_NT_THRESHOLD_BYTES);
+    }
     switch (env->A) {
-        case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
-        case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
-        case 3: e = launch_env_kernel_A<3>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
-        case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, env->P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 2: e = launch_env_kernel_A<2>(env->feat, env->niw, P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 3: e = launch_env_kernel_A<3>(env->feat, env->niw, P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
+        case 4: e = launch_env_kernel_A<4>(env->feat, env->niw, P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
         default: return fail(MARL_ERR_INVALID, "unsupported agent count");
     }
     if (e != hipSuccess) return fail_hip(e, "env kernel launch");
@@ -480,6 +488,24 @@ extern "C" int marl_env_step(marl_env_t* env, void* d_state, const void* d_actio
     static const int ablate = [] { const char* v = getenv("MARL_AMD_ABLATE"); return v ? atoi(v) & 31 : 0; }();
     return run_env_kernel(env, d_state, d_actions, action_elem_size, d_prio_override, nullptr, nullptr, d_obs,
                           d_rewards, d_terminated, d_truncated, ablate << 8, stream);
+}
+
+extern "C" int marl_env_step_many(marl_env_t* env, void* d_state, const void* d_actions, int action_elem_size,
+                                  int num_steps, float* d_obs, float* d_rewards, uint8_t* d_terminated,
+                                  uint8_t* d_truncated, const uint8_t* d_prio_override, void* stream) {
+    if (!d_actions || !d_rewards || !d_terminated || !d_truncated)
+        return fail(MARL_ERR_INVALID, "actions / rewards / terminated / truncated must not be NULL");
+    if (action_elem_size != 1 && action_elem_size != 4 && action_elem_size != 8)
+        return fail(MARL_ERR_INVALID, "action_elem_size must be 1, 4 or 8");
+    if (((uintptr_t)d_actions & (uintptr_t)(action_elem_size - 1)) != 0)
+        return fail(MARL_ERR_INVALID, "d_actions is not aligned to its element size");
+    if (((uintptr_t)d_rewards & 3u) != 0) return fail(MARL_ERR_INVALID, "d_rewards must be 4-byte aligned");
+    if (num_steps < 1 || num_steps > 65536) return fail(MARL_ERR_INVALID, "num_steps must be in [1, 65536]");
+    if (env && (((size_t)env->P.E * env->A * env->D) & 3u) != 0 && num_steps > 1)
+        return fail(MARL_ERR_INVALID, "rows of one step must be a multiple of 16 bytes for a multi-step launch "
+                                      "(every step's rows start 16-byte aligned)");
+    return run_env_kernel(env, d_state, d_actions, action_elem_size, d_prio_override, nullptr, nullptr, d_obs,
+                          d_rewards, d_terminated, d_truncated, 0, stream, num_steps);
 }
 
 extern "C" int marl_env_featurize(marl_env_t* env, void* d_state, float* d_obs, void* stream) {

@@ -838,209 +838,16 @@ __device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, cons
 // the kernel.  mode: 0 = step (+ auto-reset on truncation), 1 = reset every env,
 // 2 = featurize the stored state only.  Bits 8+ of mode are a profiling aid.
 // ---------------------------------------------------------------------------------------
-template <int A, int FEAT, int NIW>
-__global__ void __launch_bounds__(256)
-env_kernel(EnvParams P, const uint8_t* __restrict__ tab_g, const uint8_t* __restrict__ aux_g,
-           uint32_t* __restrict__ state,
-           const void* __restrict__ actions, int act_size, const uint8_t* __restrict__ prio,
-           const uint8_t* __restrict__ spawn_ov, const uint8_t* __restrict__ dir_ov,
-           float* __restrict__ obs, float* __restrict__ rewards, uint8_t* __restrict__ terminated,
-           uint8_t* __restrict__ truncated, int mode) {
-    using G = FeatGeom<A, FEAT>;
-    constexpr int D = G::D, BLK = G::BLK, NW = G::NW;
-    constexpr int NRAW = 3 + (A + 1) / 2 + NIW;
-    extern __shared__ __align__(16) uint8_t smem[];
-
-    // A wave serves EPW whole envs; an env takes LPE lanes (A rounded up to a power of two, the
-    // spare lanes idle), so that the lanes of one env always share a wave.
-    constexpr int LPE = lanes_per_env(A), EPW = 64 / LPE, RPW = EPW * A;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const size_t N = (size_t)P.E * A;
-    const size_t wave_global = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    const size_t row0 = wave_global * RPW;  // first row of this wave
-    const uint32_t i = (uint32_t)lane % LPE;
-    const uint32_t env_local = (uint32_t)lane / LPE;
-    const uint32_t row_local = env_local * A + i;  // row within the wave's image
-    const bool env_on = wave_global * EPW + env_local < (size_t)P.E;
-    const bool active = i < (uint32_t)A && env_on;  // this lane has a row
-    // With three agents the env's fourth lane has no row but runs the simulation along with the
-    // others: the lanes of an env trade values through DPP moves (step_env_quad), and a lane
-    // that is switched off does not read as zero there, it reads as whatever its registers hold.
-    const bool simulates = A > 2 ? env_on : active;
-    const int e = env_on ? (int)(wave_global * EPW + env_local) : 0;
-    const size_t row = row0 + row_local;
-    const int ablate = mode >> 8;  // 1 = skip the store stream, 2 = skip the simulation (timing only)
-    mode &= 0xFF;
-#ifdef OC_STAMPS
-    uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t* stamp_out = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(prio));
-    prio = nullptr;
-    OC_STAMP(0);
-    const uint64_t wall0 = wall_clock64();
-    uint64_t wall1 = 0;
-#endif
-
-    // issue the HBM reads first so that they fly while the lookup blob is staged
-    uint32_t raw[NRAW];
-    uint32_t act[A];
-    load_raw<A, NIW>(raw, state, P.E, e);
-    // three or four agents: a lane needs its own agent's action only (act[0]), see step_env_quad
-    static_for<0, (A > 2 ? 1 : A)>([&](auto K) {
-        const size_t r = (size_t)e * A + (A > 2 ? (i < (uint32_t)A ? i : 0u) : (uint32_t)K.value);
-        act[K.value] = mode != 0    ? (uint32_t)ACT_NOOP
-                     : act_size == 8 ? (uint32_t) reinterpret_cast<const long long*>(actions)[r]
-                     : act_size == 4 ? (uint32_t) reinterpret_cast<const int*>(actions)[r]
-                                     : (uint32_t) reinterpret_cast<const uint8_t*>(actions)[r];
-    });
-
-    // the env's RNG key needs nothing from memory: computed while the loads are in flight
-    uint32_t rng_key;
-    {
-        const uint64_t g = (((uint64_t)P.env_base_hi << 32) | P.env_base_lo) + (uint64_t)e;
-        const uint32_t k = mix32(P.seed_key ^ (uint32_t)g);
-        rng_key = mix32(k ^ (uint32_t)(g >> 32));
-    }
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(tab_g);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int k = threadIdx.x; k < P.tab_bytes / 16; k += blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
-    OC_STAMP(1);
-    Lds T{smem, P};
-    uint8_t* img = smem + P.tab_bytes + wave * (RPW * D);
-
-    if (simulates && !(ablate & 2)) {
-        EnvState<A, NIW> s;
-        unpack_state<A, NIW>(s, raw);
-        s.rng.key = rng_key;
-        OC_STAMP(2);
-        if (mode == 0) {
-            uint32_t rew_idx;
-            if constexpr (A > 2) rew_idx = step_env_quad<A, NIW>(s, T, P, act[0], prio, e, i);
-            else rew_idx = step_env<A, NIW>(s, T, P, act, prio, e, i);
-            OC_STAMP(3);
-            // the reward is a function of (own events, deliveries in the env): the host summed it
-            // as Python floats in the config's list order and rounded once (csrc/capi.hip)
-            const float r = T.rew_value(rew_idx);
-            const bool trunc = s.t >= (uint32_t)P.max_steps;
-            if (active) {
-                wt_store(rewards + row, r);
-                wt_store(terminated + row, (uint8_t)0);
-                wt_store(truncated + row, (uint8_t)(trunc ? 1 : 0));
-            }
-            // vector-env semantics: a finished env restarts at once and reports the first
-            // observation of the new episode together with the done flags
-            if (trunc && P.auto_reset) reset_env<A, NIW>(s, T, P, nullptr, nullptr, aux_g, e);
-            if (i == 0) store_state<A, NIW>(s, state, P.E, e);
-        } else if (mode == 1) {
-            reset_env<A, NIW>(s, T, P, spawn_ov, dir_ov, aux_g, e);
-            if (i == 0) store_state<A, NIW>(s, state, P.E, e);
-        }
-
-        OC_STAMP(4);
-        Block<NW> blk;
-        if (active) build_block<A, FEAT, NIW>(blk, s, T, P, i);
-        OC_STAMP(5);
-        if (!active) {
-            // the spare lane of a three-agent env: nothing to write
-        } else if constexpr (FEAT == FEAT_GLOBAL && A == 2) {
-            write_row_pair<BLK, NW>(img, (uint32_t)lane, blk.w);
-        } else if constexpr (FEAT == FEAT_GLOBAL) {
-            // my block goes into every row of my env: first in my own, after the lower ids elsewhere
-            const uint32_t env_row0 = env_local * A;
-            static_for<0, A>([&](auto J) {
-                constexpr uint32_t j = J.value;
-                const uint32_t slot = (j == i) ? 0u : (i < j ? i + 1u : i);
-                write_block<BLK, NW>(img, (env_row0 + j) * D + slot * BLK, blk.w);
-            });
-        } else {
-            write_block<BLK, NW>(img, row_local * D, blk.w);
-        }
-    }
-    OC_STAMP(6);
-#ifdef OC_STAMPS
-    wall1 = wall_clock64();
-#endif
-    // A wave's row image is written and read by that wave alone (the A lanes of an env share a
-    // wave), and LDS operations of one wave complete in order: ordering within the wave is
-    // all that is needed, so waves of a workgroup start streaming as soon as they are done.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // stream the wave's rows out: 4 int8 -> 4 floats -> one 16-byte store per lane.  The stores
-    // go through a wave-uniform buffer descriptor over exactly this wave's rows (the hardware
-    // range check drops anything past the end).
-    if (row0 < N && !(ablate & 1)) {
-        const size_t rows_here = (N - row0) < (size_t)RPW ? (N - row0) : (size_t)RPW;
-        const uint32_t nfloat = (uint32_t)(rows_here * D);
-        static_assert((RPW * D) % 4 == 0, "a full group of rows is a whole number of 16-byte chunks");
-        const uint32_t nchunk = nfloat / 4;  // the tail of a short last group is handled below
-        const uint32_t* img32 = reinterpret_cast<const uint32_t*>(img);
-        // the descriptor must be provably wave-uniform (scalar registers), or every store is
-        // wrapped in a lane-by-lane loop: the wave index comes from threadIdx, so say it explicitly
-        const uint64_t out_bits = reinterpret_cast<uint64_t>(obs + row0 * D);
-        // (the builtin returns a signed int: widen through uint32_t or the low half's top bit
-        // smears over the high half of the address)
-        const uint32_t out_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)out_bits);
-        const uint32_t out_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(out_bits >> 32));
-        float* out = reinterpret_cast<float*>(((uint64_t)out_hi << 32) | (uint64_t)out_lo);
-        const uint32_t nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nchunk * 16u));
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, nbytes, 0x00020000);
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        // Fully unrolled: iteration k handles chunk k*64 + lane, so the LDS address and the store
-        // offset are the lane's base plus compile-time constants and the loop costs no address
-        // arithmetic.  Chunks past the end of a short last group are dropped by the descriptor's
-        // range check (their LDS reads return whatever lies there; it is never stored).  The
-        // constant goes into the VECTOR offset: the range check covers the vector offset plus
-        // the 12-bit instruction offset but NOT the scalar offset operand, so a constant passed
-        // there would let the tail lanes write past the group's rows.  The compiler splits the
-        // sum into a multiple of 4096 (one add per four iterations) and the instruction offset.
-        constexpr int ITERS = (RPW * D / 4 + 63) / 64;
-        const uint32_t* my = img32 + lane;
-        const uint32_t voff = (uint32_t)lane * 16u;
-        // Cache policy of the stores (measured on MI355X): below the size of the last-level
-        // cache a write-through-to-system-scope store (sc1) is fastest, the rows then sit in
-        // that cache for the consumer; a larger observation tensor streams to HBM and does
-        // better with the non-temporal hint added.  The host picks by tensor size.
-        auto stream = [&](auto AUX) {
-            static_for<0, ITERS>([&](auto K) {
-                constexpr int k = K.value;
-                const uint32_t v = my[k * 64];
-                f32x4 f;
-                f.x = (float)(int)(int8_t)(v);
-                f.y = (float)(int)(int8_t)(v >> 8);
-                f.z = (float)(int)(int8_t)(v >> 16);
-                f.w = (float)(int)(int8_t)(v >> 24);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f), rsrc, voff + (uint32_t)(k * 1024), 0,
-                                                       decltype(AUX)::value);
-            });
-        };
-        if (P.stream_nt) stream(std::integral_constant<int, STORE_SC1 | STORE_NT>{});
-        else stream(std::integral_constant<int, STORE_SC1>{});
-        // a short last group can leave up to 3 floats past the last full chunk
-        const uint32_t rem = nfloat & 3u;
-        if (rem && lane < (int)rem) {
-            const uint32_t idx = nchunk * 4 + lane;
-            out[idx] = (float)(int)(int8_t)img[idx];
-        }
-    }
-#ifdef OC_STAMPS
-    OC_STAMP(7);
-    if (stamp_out && lane == 0) {
-        uint64_t* o = stamp_out + wave_global * 16;
-        static_for<0, 8>([&](auto K) { o[K.value] = stamp[K.value]; });
-        o[8] = wall_clock64();
-        o[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
-        o[10] = wall0;
-        o[11] = wall1;
-        o[12] = __builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_ID
-    }
-#endif
-}
+#define OC_KERNEL_NAME env_kernel
+#define OC_MANY 0
+#include "env_kernel_body.inc"
+#undef OC_KERNEL_NAME
+#undef OC_MANY
+#define OC_KERNEL_NAME env_kernel_many
+#define OC_MANY 1
+#include "env_kernel_body.inc"
+#undef OC_KERNEL_NAME
+#undef OC_MANY
 
 // ---------------------------------------------------------------------------------------
 // dispatch
@@ -1063,14 +870,21 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     if (lds > configured[dev]) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<A, FEAT, NIW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel_many<A, FEAT, NIW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         configured[dev] = lds;
     }
     const size_t N = (size_t)P.E * A;
     const size_t rows_per_block = (size_t)waves * RPW;
     const unsigned grid = (unsigned)((N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((env_kernel<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
-                       actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
+    if (P.nsteps > 1 && (mode & 0xFF) == 0)
+        hipLaunchKernelGGL((env_kernel_many<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
+                           actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
+    else
+        hipLaunchKernelGGL((env_kernel<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
+                           actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
     return hipGetLastError();
 }
 

@@ -286,6 +286,26 @@ class BatchedOvercookedVecEnv:
                                          _ptr(rewards), _ptr(terminated), _ptr(truncated), _ptr(prio_override),
                                          self._stream()), "marl_env_step")
 
+    def step_many_into(self, actions, obs, rewards, terminated, truncated, prio_override=None):
+        """`actions.shape[0]` consecutive steps in one launch, for action sequences known up front
+        (random-action rollouts, replays): actions [K, N]; obs float32 [K, N, D]; rewards float32
+        [K, N]; terminated / truncated bool or uint8 [K, N]; all preallocated and contiguous on this
+        env's device.  Same results as K `step_into` calls; a step's simulation overlaps the row
+        stores of the step before it."""
+        K = int(actions.shape[0])
+        for name, t, shape in (("actions", actions, (K, self.N)), ("obs", obs, (K, self.N, self.D)),
+                               ("rewards", rewards, (K, self.N)), ("terminated", terminated, (K, self.N)),
+                               ("truncated", truncated, (K, self.N))):
+            if tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"{name} must be a contiguous tensor of shape {shape} on {self.device}")
+        if obs.dtype != torch.float32 or rewards.dtype != torch.float32:
+            raise ValueError("obs and rewards must be float32")
+        if prio_override is not None and (tuple(prio_override.shape) != (K, self.N) or prio_override.dtype != torch.uint8):
+            raise ValueError(f"prio_override must be uint8 of shape {(K, self.N)}")
+        _lib.check(self._L.marl_env_step_many(self._h, _ptr(self.state), _ptr(actions), actions.element_size(), K,
+                                              _ptr(obs), _ptr(rewards), _ptr(terminated), _ptr(truncated),
+                                              _ptr(prio_override), self._stream()), "marl_env_step_many")
+
     def featurize(self, out=None):
         obs = self._new_obs(out)
         _lib.check(self._L.marl_env_featurize(self._h, _ptr(self.state), _ptr(obs), self._stream()),

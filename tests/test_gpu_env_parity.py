@@ -362,3 +362,38 @@ def test_step_writes_into_caller_buffer_and_rejects_bad_ones():
         env.step(act[:-1])
     with pytest.raises(ValueError):
         env.step(act, out=torch.zeros((env.N, env.D), dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("layout,A,feature,E", [
+    ("overcooked_cramped_room_v0", 2, "global_obs", 258), ("overcooked_coordination_ring_v0", 4, "local_obs", 99),
+    ("overcooked_coordination_ring_v0", 3, "global_obs", 76), ("overcooked_cramped_room_v0", 1, "local_obs", 64),
+    ("large_overcooked_layout", 4, "global_obs", 33), ("overcooked_cramped_room_v0", 2, "only_direction", 70),
+])
+def test_many_steps_in_one_launch(layout, A, feature, E):
+    """marl_env_step_many against the same number of marl_env_step calls: every output of every
+    step and the final state, bit for bit, with episodes ending inside the launch; then both
+    carry on from the state the multi-step launch left."""
+    from marl_amd.env import BatchedOvercookedVecEnv
+
+    rows = get_layout(layout)
+    K = 23
+    one = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=9, seed=4, env_index_base=17)
+    many = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=9, seed=4, env_index_base=17)
+    N, D = one.N, one.D
+    dev = one.device
+    one.reset(); many.reset()
+    g = torch.Generator(device="cpu").manual_seed(E)
+    for rnd in range(2):
+        acts = torch.randint(0, 7, (K, N), generator=g).to(dev)
+        prio = torch.randint(0, 256, (K, N), generator=g, dtype=torch.uint8).to(dev) if rnd == 1 and A > 1 else None
+        obs1 = torch.empty((K, N, D), device=dev); rew1 = torch.empty((K, N), device=dev)
+        te1 = torch.empty((K, N), dtype=torch.bool, device=dev); tr1 = torch.empty_like(te1)
+        obs2, rew2, te2, tr2 = torch.empty_like(obs1), torch.empty_like(rew1), torch.ones_like(te1), torch.empty_like(tr1)
+        for k in range(K):
+            one.step_into(acts[k], obs1[k], rew1[k], te1[k], tr1[k], prio_override=None if prio is None else prio[k])
+        many.step_many_into(acts, obs2, rew2, te2, tr2, prio_override=prio)
+        assert torch.equal(obs1, obs2) and torch.equal(rew1, rew2) and torch.equal(tr1, tr2) and not te2.any()
+        assert tr1.any(), "no episode ended inside the launch"
+        assert torch.equal(one.state, many.state)
+    with pytest.raises(ValueError):
+        many.step_many_into(acts[:, :-1], obs2, rew2, te2, tr2)
