@@ -60,6 +60,47 @@ def cpu_baseline(layout_rows, A, feature, E, seed, threads):
     }
 
 
+def rows_kept_leg(env, actions, rew, term, trunc, N, D, B, ring=32, steps=512):
+    """The same launches when every step's rows are kept (a rollout store) instead of being
+    overwritten two steps later: the rows then have to drain to HBM, whereas two alternating
+    buffers of the headline size stay in the 256 MiB last-level cache.  Reported next to the
+    headline so that both regimes are on record; `step_many` is the multi-step launch
+    (marl_env_step_many, 32 steps per launch) writing the same rows."""
+    import torch
+
+    dev = rew.device
+    store = torch.empty((ring, N, D), dtype=torch.float32, device=dev)
+    R = actions.shape[0]
+    for i in range(2 * ring):
+        env.step_into(actions[i % R], store[i % ring], rew, term, trunc)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for i in range(steps):
+        env.step_into(actions[i % R], store[i % ring], rew, term, trunc)
+    ev1.record()
+    torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) * 1e3 / steps
+    out = {"obs_ring": ring, "us_per_launch": us, "value": N / us * 1e6, "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
+    if (N * D) % 4 == 0 and R >= ring:
+        rew_k = torch.empty((ring, N), dtype=torch.float32, device=dev)
+        te_k = torch.empty((ring, N), dtype=torch.bool, device=dev)
+        tr_k = torch.empty_like(te_k)
+        acts_k = actions[:ring].contiguous()
+        reps = max(steps // ring, 2)
+        env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
+        ev1.record()
+        torch.cuda.synchronize()
+        us_m = ev0.elapsed_time(ev1) * 1e3 / (reps * ring)
+        out["step_many"] = {"steps_per_launch": ring, "us_per_step": us_m, "value": N / us_m * 1e6,
+                            "frac": N * B / us_m / 1e3 / HBM_PEAK_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,9 +248,12 @@ def main():
                          "bytes_per_agent_step": B, "kernel": f"env_kernel<{A} agents, {args.feature}> (step+featurize)",
                          "us_per_launch": launch_s * 1e6},
         }
+        out["config"]["obs_ring"] = RING
         if policy is not None:
             # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
             out["roofline"] = None
+        elif world == 1 and RING == 2 and not args.graph:
+            out["rows_kept"] = rows_kept_leg(env, actions, rew, term, trunc, N, D, B)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234, threads)
