@@ -69,6 +69,7 @@ def rows_kept_leg(env, actions, rew, term, trunc, N, D, B, ring=32, steps=512):
     import torch
 
     dev = rew.device
+    ring = int(max(4, min(ring, (8 << 30) // (N * D * 4))))  # at most 8 GB of rows
     store = torch.empty((ring, N, D), dtype=torch.float32, device=dev)
     R = actions.shape[0]
     for i in range(2 * ring):
@@ -113,6 +114,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rows-kept", action="store_true",
+                    help="skip the extra leg that times the kept-rows regime (profiling runs: keeps the traced launches uniform)")
     ap.add_argument("--obs-ring", type=int, default=2,
                     help="observation buffers the steps cycle through (2: the next step overwrites the rows the consumer "
                          "has just read, they never have to leave the last-level cache; 128: every step's rows are kept "
@@ -252,7 +255,7 @@ def main():
         if policy is not None:
             # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
             out["roofline"] = None
-        elif world == 1 and RING == 2 and not args.graph:
+        elif world == 1 and RING == 2 and not args.graph and not args.no_rows_kept:
             out["rows_kept"] = rows_kept_leg(env, actions, rew, term, trunc, N, D, B)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

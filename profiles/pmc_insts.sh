@@ -1,7 +1,7 @@
 # Instruction-mix counters of the fused kernel (one pass, 8 SQ counters)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_insts
-timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_insts -o insts -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline > gpurun_out/pmc_insts/bench.json 2> gpurun_out/pmc_insts/err.txt
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_insts -o insts -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-rows-kept > gpurun_out/pmc_insts/bench.json 2> gpurun_out/pmc_insts/err.txt
 python3 - <<'PY'
 import csv, collections
 rows = list(csv.DictReader(open('gpurun_out/pmc_insts/insts_counter_collection.csv')))

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_policy
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 bench.py --mode policy --steps 256 --warmup 32 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 bench.py --mode policy --steps 256 --warmup 32 --no-cpu-baseline --no-rows-kept > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
 python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open("gpurun_out/prof_policy/t_kernel_stats.csv")))
