@@ -60,6 +60,28 @@ __global__ void __launch_bounds__(256) own_region_paced(float* out, size_t nbyte
     }
 }
 
+// own region, but wave w starts writing only when at most WINDOW waves below it are unfinished:
+// the chip's write front stays WINDOW x 51.7 KB wide.  Bounded spin (a wave that waited too long
+// goes ahead), the counter wraps to zero when the last wave has signed off.
+__device__ unsigned int g_done;
+template <int WINDOW>
+__global__ void __launch_bounds__(256) own_region_windowed(float* out, size_t nbytes) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = blockIdx.x * 4 + (threadIdx.x >> 6), total = gridDim.x * 4;
+    int spins = 0;
+    while ((int)(wave - __hip_atomic_load(&g_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > WINDOW && ++spins < 20000)
+        __builtin_amdgcn_s_sleep(8);
+    const size_t base = (size_t)wave * 51712;
+    f32x4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+#pragma unroll
+    for (int k = 0; k < 51; ++k) {
+        const size_t off = base + (size_t)k * 1024 + lane * 16;
+        if (off < base + 51712 && off < nbytes) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out) + off) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicInc(&g_done, total - 1);
+}
+
 // long-lived workgroups, the whole grid sweeps memory together: iteration i of workgroup b writes
 // the 4 KiB chunk i * gridDim + b
 __global__ void __launch_bounds__(256) grid_stride(float* out, size_t nbytes) {
@@ -107,6 +129,10 @@ int main() {
                run(short_wg_shifted<0>, b0, b1, nbytes, g4, it), run(short_wg_shifted<1>, b0, b1, nbytes, g4, it),
                run(short_wg_shifted<2>, b0, b1, nbytes, g4, it), run(short_wg_shifted<4>, b0, b1, nbytes, g4, it),
                run(short_wg_shifted<8>, b0, b1, nbytes, g4, it), run(short_wg_shifted<16>, b0, b1, nbytes, g4, it));
+        printf("%4zu MB  own region, write front limited to 64 waves: %.2f  160: %.2f  320: %.2f  640: %.2f  1280: %.2f  2560: %.2f TB/s\n", nbytes / 1000000,
+               run(own_region_windowed<64>, b0, b1, nbytes, g, it), run(own_region_windowed<160>, b0, b1, nbytes, g, it),
+               run(own_region_windowed<320>, b0, b1, nbytes, g, it), run(own_region_windowed<640>, b0, b1, nbytes, g, it),
+               run(own_region_windowed<1280>, b0, b1, nbytes, g, it), run(own_region_windowed<2560>, b0, b1, nbytes, g, it));
         hipFree(b0); hipFree(b1);
     }
     return 0;
