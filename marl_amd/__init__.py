@@ -11,6 +11,7 @@ Public surface (mirrors the reference's modules for this path):
   marl_amd.agents         MAPPO, CMAPPO
   marl_amd.rollout        agent_environment_loop
   marl_amd.train          command-line entry point
+  marl_amd.replay         replays a recorded episode (spawns, actions, serving order) and compares
   marl_amd.evaluate       plays a saved policy (the reference's tests/test_load.py)
 The simulation, featurisation, GAE, event bookkeeping, sampling and the PPO loss run in marl_amd/libmarl_amd.so (hand-written HIP for
 gfx950, C ABI in include/marl_amd.h); importing the package does not load it, using it does.
