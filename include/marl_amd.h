@@ -1,6 +1,7 @@
 /*
- * marl_amd.h -- C ABI of libmarl_amd.so: batched Overcooked step / reset / featurize and the
- * GAE pass for MI355X (gfx950).
+ * marl_amd.h -- C ABI of libmarl_amd.so: batched Overcooked step / reset / featurize, the GAE
+ * pass, and three small passes of the rollout / update loop (reward-event bookkeeping, action
+ * sampling, the PPO minibatch loss) for MI355X (gfx950).
  *
  * The reference (loganwoudstra/MARL) is pure Python and has no FFI of its own; the boundary
  * it does have is the duck-typed vector env returned by main.py:66-96 `make_vector_env`
