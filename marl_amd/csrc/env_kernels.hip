@@ -440,8 +440,8 @@ __device__ __forceinline__ uint32_t step_env(EnvState<A, NIW>& s, const Lds& T, 
 // stay identical.  Same rules and same results as step_env; about 40 % fewer instructions than
 // every lane working through every agent.  Returns the reward-table index of agent i.
 // ---------------------------------------------------------------------------------------
-// value held by lane K of the caller's quad.  All four lanes must be running: a lane that is
-// switched off is not read as zero, it yields whatever its registers hold.
+// value held by lane K of the caller's quad.  All four lanes must be running (see the kernel body:
+// results went wrong with one of them switched off).
 template <int K>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, K * 0x55, 0xF, 0xF, true);
