@@ -440,13 +440,13 @@ __device__ __forceinline__ uint32_t step_env(EnvState<A, NIW>& s, const Lds& T, 
 // stay identical.  Same rules and same results as step_env; about 40 % fewer instructions than
 // every lane working through every agent.  Returns the reward-table index of agent i.
 // ---------------------------------------------------------------------------------------
-// value held by lane K of the caller's quad.  All four lanes must be running (see the kernel body:
-// results went wrong with one of them switched off).
+// value held by lane K of the caller's quad (a switched-off lane reads as zero)
 template <int K>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, K * 0x55, 0xF, 0xF, true);
 }
-// OR / sum over the lanes of the quad
+// OR / sum over the lanes of the quad, as a two-step butterfly: all four lanes must be running,
+// partial results pass through each of them
 __device__ __forceinline__ uint32_t quad_or(uint32_t x) {
     x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
     x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]

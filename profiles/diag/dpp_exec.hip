@@ -29,6 +29,24 @@ __global__ void probe_or(int* out, const int* in) {
     out[lane] = got;
 }
 
+// the same OR written as the two VOP2 DPP instructions the compiler emits for it, on a register
+// that holds 1000 + lane in the switched-off lane
+__global__ void probe_or_vop2(int* out) {
+    const int lane = threadIdx.x;
+    unsigned x = 1000u + lane;
+    asm volatile("" : "+v"(x));
+    int got = -1;
+    if ((lane & 3) != 3) {
+        const unsigned y = ((lane & 3) == 1) ? 1u : 0u;
+        asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\t"
+                     "v_or_b32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+                     "v_or_b32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(x) : "v"(y));
+        got = (int)x;
+    }
+    out[lane] = got;
+}
+
 int main() {
     int* d;
     int h[64];
@@ -46,5 +64,10 @@ int main() {
     printf("quad-wide OR of (0, 1, 0, off): ");
     for (int i = 0; i < 8; ++i) printf("%d ", h[i]);
     printf("\n(1 1 1 -1 expected if switched-off lanes read as zero)\n");
+    hipLaunchKernelGGL(probe_or_vop2, dim3(1), dim3(64), 0, 0, d);
+    hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    printf("the same with v_or_b32_dpp on a register whose switched-off lane holds 1000 + lane: ");
+    for (int i = 0; i < 8; ++i) printf("%d ", h[i]);
+    printf("\n(1 1 1 -1 if the switched-off lane reads as zero; 1003-ish values if its register is read)\n");
     return 0;
 }
