@@ -1,16 +1,22 @@
 """Device-resident rollout driver, counterpart of the reference's
 ``agent_environment.agent_environment_loop`` (agent_environment.py:12-130).
 
-Same control flow -- act, step, count reward events, store, global reset when env 0 finishes,
-update every ``num_steps`` -- with the per-step host round trips removed:
+Same control flow -- act, step, count reward events, store, global reset one step after env 0
+finishes, update every ``num_steps`` -- with the per-step host round trips removed:
   * observations, rewards and done flags never leave the GPU (the reference does two
     host-to-device copies, one device-to-host copy and a Python loop over rows per step,
     agent_environment.py:50,63,106-107);
   * the env kernel writes the next observation straight into the rollout store's next row;
   * episode statistics accumulate on the device and are read back once per episode;
   * when a rollout is launch-bound (few rows per launch) its steps are captured once into
-    hipGraphs and replayed: one graph per (first row, length) segment, since the driver's
-    restart at the end of an episode cuts a rollout in two.
+    hipGraphs and replayed: a rollout without an episode end is one graph; the driver's restart
+    at an episode end cuts a rollout in two, and the pieces are replayed from graphs of aligned
+    power-of-two runs of steps (a bounded set, whatever the episode length).
+The restart keeps the reference's one-step lag (agent_environment.py:84-88,107): the driver tests
+the done flags of the PREVIOUS step, so after the step on which every env truncates (and the
+vector env has restarted them by itself) it acts and steps once more -- that row is stored with
+dones = 1, its rewards count towards the old episode -- and only then resets all envs.  An
+episode therefore spans max_steps + 1 driver steps and env.step calls.
 Episode statistics keep the reference's definition (agent_environment.py:66-76,86-104: rows
 0..1 only, whatever the agent count; a delivery is any reward >= 1, a plating == 0.3, an
 onion-in-pot == 0.1; the return is the sum over steps of the mean reward of those rows) and add
@@ -24,6 +30,21 @@ import torch
 from . import dist_utils
 from .env import OBS_KEY
 from .episode_stats import EpisodeStats
+
+
+def aligned_runs(first, count):
+    """[first, first + count) cut into runs (start, length) whose length is a power of two and
+    whose start is a multiple of it: at most 2 log2(count) runs, and over all possible segments
+    of a T-step rollout fewer than 2 T distinct ones."""
+    out = []
+    while count > 0:
+        size = 1
+        while size * 2 <= count and first % (size * 2) == 0:
+            size *= 2
+        out.append((first, size))
+        first += size
+        count -= size
+    return out
 
 
 class ScalarLog:
@@ -62,6 +83,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     if log and writer is None:
         writer = make_writer(log_dir)
     max_steps = getattr(env, "max_steps", 1000)
+    episode_span = max_steps + 1  # driver steps per episode: the reference notices an episode's end one step late
     # "auto": replay the rollout from hipGraphs when it is launch-bound (few rows per launch)
     graph_mode = getattr(args, "graph_rollout", "off")
     # and the job is a single rank ("on" forces it; multi-rank replay is exercised over gloo only)
@@ -115,13 +137,8 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     graphs = {}
     pool = None
 
-    def run_segment(first, count, warm):
-        """steps [first, first + count) of the current rollout"""
+    def replay_run(first, count):
         nonlocal pool
-        if not (use_graphs and warm):
-            for step in range(first, first + count):
-                one_step(step)
-            return
         g = graphs.get((first, count))
         if g is None:
             # capture records the launches without running them; the replay below does the work
@@ -134,6 +151,18 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 pool = g.pool()
             graphs[(first, count)] = g
         g.replay()
+
+    def run_segment(first, count, warm):
+        """steps [first, first + count) of the current rollout"""
+        if not (use_graphs and warm):
+            for step in range(first, first + count):
+                one_step(step)
+            return
+        if count == collect_steps:
+            replay_run(first, count)  # a whole rollout: one graph
+        else:
+            for f, c in aligned_runs(first, count):
+                replay_run(f, c)
         buf.ptr = (first + count) % buf.max_size
         buf.size = min(first + count, buf.max_size)
 
@@ -157,13 +186,16 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         if direct:
             agent.begin_direct_rollout()
         while step < collect_steps:
-            count = min(collect_steps - step, max_steps - steps_in_episode)
+            count = min(collect_steps - step, episode_span - steps_in_episode)
             run_segment(step, count, warm=update_index > 0)  # the first rollout runs eagerly (lazy library set-up)
             step += count
             steps_in_episode += count
-            if steps_in_episode >= max_steps:
-                # every env was stepped in lockstep and has just truncated; like the reference,
-                # restart all of them once more from the driver (agent_environment.py:86-88)
+            if steps_in_episode >= episode_span:
+                # All envs run in lockstep: they truncated (and restarted themselves) on driver step
+                # max_steps of this episode, and the step just done is the one the reference makes
+                # before it notices (its test reads the previous step's flags,
+                # agent_environment.py:84-88,107).  Now it restarts every env from the driver; the
+                # reset observation replaces the one that step returned.
                 env.reset(out=slot(step))
                 totals, first_rows = stats.raw()
                 tot_all = totals.to(torch.float64)

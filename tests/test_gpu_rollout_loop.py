@@ -1,0 +1,98 @@
+"""The device-resident rollout driver (marl_amd/rollout.py) against the CPU restatement of the
+reference's loop (oracle/rollout_loop.py, after agent_environment.py:34-112) run on the CPU oracle
+env with the same actions: every stored row, the carried observation handed to update(), and the
+episode statistics, across updates and episode ends -- including the reference's one-step-late
+restart (an episode is max_steps + 1 driver steps; the row after a truncation holds the restarted
+env's first observation with dones = 1)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler, layout="overcooked_cramped_room_v0",
+           feature="global_obs", seed=9):
+    from marl_amd.agents import MAPPO
+    from marl_amd.env import make_env, make_vector_env
+    from marl_amd.layouts import get_layout
+    from marl_amd.policy import Agent
+    from marl_amd.rollout import agent_environment_loop
+    from marl_amd.rollout_buffer import Buffer
+    from oracle.rollout_loop import OracleDictEnv, ReplayAgent, reference_rollout_loop
+
+    dev = torch.device("cuda:0")
+    env = make_env(A, layout, feature, max_steps=max_steps)
+    snaps = []
+
+    class Recorder(MAPPO):
+        def update(self, next_obs):  # keep what was collected, learn nothing
+            snap = {k: getattr(self.buffer, k + "_buff").clone() for k in
+                    ("obs", "actions", "rewards", "dones", "logprobs", "values")}
+            snap["next_obs"] = next_obs.clone()
+            assert self.buffer.ptr == 0 and self.buffer.size == T  # a full rollout was stored
+            snaps.append(snap)
+            self.buffer.reset()
+
+    vec = make_vector_env(E, env, seed=seed, device=dev)
+    torch.manual_seed(0)
+    net = Agent(vec.single_observation_space, vec.single_action_space, A, E).to(dev)
+    if fused_sampler:
+        net.use_fused_sampling(77)
+    buf = Buffer(vec.D, A, E, max_size=T, device=dev)
+    args = types.SimpleNamespace(num_steps=T, num_envs=E, num_agents=A, log=False, graph_rollout=graph_rollout)
+    agent = Recorder(vec, None, net, buf, None, None, batch_size=E * A * T, num_agents=A, args=args)
+    assert agent.can_act_into() == fused_sampler
+    torch.manual_seed(1)
+    returns, freq = agent_environment_loop(agent, vec, dev, num_update=updates, args=args)
+    assert len(snaps) == updates
+
+    # the reference's loop, restated, on the CPU env with the recorded actions
+    ora = oracle_mod.OracleVecEnv(get_layout(layout), A, feature, max_steps=max_steps, num_envs=E, seed=seed)
+    ora.reset()  # make_vector_env issues one reset of its own (main.py:95) before the loop's
+    replay = ReplayAgent([s["actions"].cpu().numpy().astype(np.int64) for s in snaps],
+                         [s["logprobs"].cpu().numpy() for s in snaps], [s["values"].cpu().numpy() for s in snaps])
+    log = []
+    ref_returns, ref_freq = reference_rollout_loop(replay, OracleDictEnv(ora), updates, T, log=log)
+    return snaps, replay.snaps, returns, freq, ref_returns, ref_freq, net, log
+
+
+@pytest.mark.parametrize("fused_sampler", [False, True])
+@pytest.mark.parametrize("graph_rollout", ["off", "on"])
+def test_stored_rollouts_match_the_reference_loop(oracle_mod, graph_rollout, fused_sampler):
+    E, A, T, updates, max_steps = 8, 2, 16, 5, 10
+    snaps, ref, returns, freq, ref_returns, ref_freq, net, log = _drive(oracle_mod, E, A, T, updates, max_steps,
+                                                                       graph_rollout, fused_sampler)
+    assert [x[0] for x in log].count("reset") == 1 + (T * updates) // (max_steps + 1)
+    for u, (got, want) in enumerate(zip(snaps, ref)):
+        for k in ("obs", "actions", "rewards", "dones", "next_obs"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+        # log-probabilities and values are those of the policy on the stored observations
+        with torch.no_grad():
+            _, lp, _, v = net.get_action_and_value(got["obs"].reshape(-1, got["obs"].shape[-1]),
+                                                   got["actions"].reshape(-1).long())
+        torch.testing.assert_close(got["logprobs"].reshape(-1), lp, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got["values"].reshape(-1), v.squeeze(1), rtol=1e-5, atol=1e-6)
+    # 80 steps = 7 episodes of 11 driver steps; the row after each truncation carries dones = 1
+    dones = np.concatenate([s["dones"][:, 0].cpu().numpy() for s in snaps])
+    assert list(np.nonzero(dones)[0]) == [k for k in range(T * updates) if k % (max_steps + 1) == max_steps]
+    assert len(returns) == len(ref_returns) == 7
+    assert returns == ref_returns
+    for k in ("frequency_delivery_per_episode", "frequency_plated_per_episode", "frequency_ingredient_in_pot_per_episode"):
+        assert [float(x) for x in freq[k]] == [float(x) for x in ref_freq[k]], k
+
+
+def test_four_agents_local_obs_and_uneven_lengths(oracle_mod):
+    """Another layout, agent count and feature set; rollout length that is no power of two (the
+    graph-replayed segments are cut into aligned power-of-two runs) and an episode length that
+    divides nothing."""
+    E, A, T, updates, max_steps = 5, 4, 12, 6, 7
+    snaps, ref, returns, _, ref_returns, _, _, _ = _drive(oracle_mod, E, A, T, updates, max_steps, "on", True,
+                                                         layout="overcooked_coordination_ring_v0", feature="local_obs",
+                                                         seed=21)
+    for u, (got, want) in enumerate(zip(snaps, ref)):
+        for k in ("obs", "actions", "rewards", "dones", "next_obs"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+    assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)

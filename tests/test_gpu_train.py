@@ -30,74 +30,6 @@ def test_training_runs_and_logs(tmp_path, algorithm, layout):
     assert any(n.endswith("_returns_seed_3.csv") for n in files)
 
 
-@pytest.mark.parametrize("fused_sampler", [False, True])
-@pytest.mark.parametrize("graph_rollout", ["off", "on"])
-def test_rollout_buffer_matches_manual_loop(graph_rollout, fused_sampler):
-    """The driver's zero-copy hand-offs (eager, and replayed from hipGraphs) store exactly what a
-    plain step/copy loop would store, across updates and episode ends: observations written by
-    the env kernel into the next row and, with the fused sampler, rewards, log-probabilities,
-    values and done flags written into their rows by the kernels that produce them."""
-    import types
-
-    from marl_amd.agents import MAPPO
-    from marl_amd.env import OBS_KEY, make_env, make_vector_env
-    from marl_amd.policy import Agent
-    from marl_amd.rollout import agent_environment_loop
-    from marl_amd.rollout_buffer import Buffer
-
-    dev = torch.device("cuda:0")
-    E, A, T, updates = 8, 2, 16, 4
-    env = make_env(A, "overcooked_cramped_room_v0", "global_obs", max_steps=10)
-
-    class Recorder(MAPPO):
-        snaps = []
-
-        def update(self, next_obs):  # keep what was collected, learn nothing
-            snap = {k: getattr(self.buffer, k).clone() for k in
-                    ("obs_buff", "actions_buff", "rewards_buff", "dones_buff", "logprobs_buff", "values_buff")}
-            snap["next_obs"] = next_obs.clone()
-            assert self.buffer.ptr == 0 and self.buffer.size == T  # a full rollout was stored
-            self.snaps.append(snap)
-            self.buffer.reset()
-
-    Recorder.snaps = []
-    vec = make_vector_env(E, env, seed=9, device=dev)
-    torch.manual_seed(0)
-    net = Agent(vec.single_observation_space, vec.single_action_space, A, E).to(dev)
-    if fused_sampler:
-        net.use_fused_sampling(77)
-    buf = Buffer(vec.D, A, E, max_size=T, device=dev)
-    args = types.SimpleNamespace(num_steps=T, num_envs=E, num_agents=A, log=False, graph_rollout=graph_rollout)
-    agent = Recorder(vec, None, net, buf, None, None, batch_size=E * A * T, num_agents=A, args=args)
-    assert agent.can_act_into() == fused_sampler
-    torch.manual_seed(1)
-    returns, _ = agent_environment_loop(agent, vec, dev, num_update=updates, args=args)
-    assert len(agent.snaps) == updates and len(returns) == updates * T // 10
-
-    # replay by hand with the same action stream
-    vec2 = make_vector_env(E, env, seed=9, device=dev)
-    obs, _ = vec2.reset()
-    obs = obs[OBS_KEY]
-    dones = torch.zeros(E * A, device=dev)
-    steps_in_ep = 0
-    for u, snap in enumerate(agent.snaps):
-        for t in range(T):
-            assert torch.equal(snap["obs_buff"][t], obs), f"stored observation {u}/{t} differs"
-            assert torch.equal(snap["dones_buff"][t], dones), f"stored done flags {u}/{t} differ"
-            with torch.no_grad():
-                _, lp, _, v = net.get_action_and_value(obs, snap["actions_buff"][t].long())
-            torch.testing.assert_close(snap["logprobs_buff"][t], lp, rtol=1e-5, atol=1e-6)
-            torch.testing.assert_close(snap["values_buff"][t], v.squeeze(1), rtol=1e-5, atol=1e-6)
-            o, r, te, tr, _ = vec2.step(snap["actions_buff"][t].long())
-            assert torch.equal(snap["rewards_buff"][t], r)
-            steps_in_ep += 1
-            if steps_in_ep == 10:
-                o, _ = vec2.reset()
-                steps_in_ep = 0
-            obs, dones = o[OBS_KEY], (te | tr).float()
-        assert torch.equal(snap["next_obs"], obs)
-
-
 def test_numpy_io_mode_runs_a_reference_shaped_loop():
     """The host-array mode accepts and returns what agent_environment.py:34-36,50-53,106-107
     handles: numpy actions in, numpy obs dict / rewards / terminated / truncated out."""
