@@ -171,6 +171,23 @@ int marl_reward_events(const float *d_rewards, int num_envs, int num_agents, uin
 size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
 
 /*
+ * marl_reward_events for callers that cannot allocate device memory or carry a workspace along:
+ * code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  Same arguments and bit-identical results, minus d_workspace:
+ * the per-chunk partial sums go to an 8 KiB array that is part of the library's device image
+ * (every GPU the library is used on holds its own copy until the process ends).  The call
+ * allocates nothing and frees nothing.  At most MARL_REWARD_EVENTS_NOALLOC_MAX_ROWS rows
+ * (num_envs * num_agents) per call; more is refused with MARL_ERR_INVALID.  All calls on one GPU
+ * share that array: calls that may overlap on one GPU (different streams, different host
+ * threads) race on it and must be serialised by the caller; calls on one stream are ordered and
+ * safe.  The first call on each device looks the array's address up (no stream work, no
+ * allocation); make that call outside graph capture.
+ */
+#define MARL_REWARD_EVENTS_NOALLOC_MAX_ROWS (1 << 24)
+int marl_reward_events_noalloc(const float *d_rewards, int num_envs, int num_agents, uint64_t *d_totals,
+                               double *d_first_rows, void *stream);
+
+/*
  * The sampling half of MAPPO.act (agents/MAPPO.py:58-77 -> model.py:52-56): for every row of
  * d_logits (float32, row-major, row_stride floats from one row to the next; 0 = num_actions)
  * draw an action from Categorical(logits=row[0:num_actions]) and report its log-probability

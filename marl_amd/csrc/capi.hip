@@ -58,6 +58,10 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+namespace oc {
+// for the entry points that live next to their kernels (csrc/stats_kernels.hip)
+int set_error(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace oc
 static int fail_hip(hipError_t e, const char* what) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return MARL_ERR_HIP;

@@ -10,7 +10,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <string>
+
+#include "../../include/marl_amd.h"
+
 namespace oc {
+int set_error(int code, const std::string& msg);  // csrc/capi.hip: records marl_last_error() of this thread
 
 constexpr int EVENT_BLOCK = 256;
 
@@ -107,4 +113,63 @@ hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* pa
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// The same pass for callers that may not allocate (code under hipGraph capture, serving loops,
+// harnesses with a no-allocation rule): the per-chunk partial sums, the one piece of scratch this
+// pass needs, live in a file-scope device array instead of a caller-supplied workspace.  Every
+// GPU the library runs on holds its own copy of the array (8 KiB) at its own address until the
+// process ends; the host learns that address once per device and passes it to the kernels like
+// any other buffer.
+// ---------------------------------------------------------------------------------------
+constexpr int EVENT_SCRATCH_CHUNKS = 256;  // reward_event_chunks() never returns more
+static __device__ __align__(256) uint64_t scratch[EVENT_SCRATCH_CHUNKS * 4];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static uint64_t* g_scratch_ptr[MAX_DEVICES] = {nullptr};  // device address of `scratch`, per device
+
+// device address of the current device's copy of `scratch` (looked up on the first call per device)
+static int scratch_for_current_device(uint64_t** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(MARL_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    if (dev < 0 || dev >= MAX_DEVICES) return set_error(MARL_ERR_INVALID, "device index outside [0, 64)");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return set_error(MARL_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<uint64_t*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return MARL_OK;
+}
+
 }  // namespace oc
+
+extern "C" int marl_reward_events_noalloc(const float* d_rewards, int num_envs, int num_agents, uint64_t* d_totals,
+                                          double* d_first_rows, void* stream) {
+    using namespace oc;
+    if (!d_rewards || !d_totals) return set_error(MARL_ERR_INVALID, "NULL argument to marl_reward_events_noalloc");
+    if (num_envs <= 0 || num_agents <= 0)
+        return set_error(MARL_ERR_INVALID, "num_envs and num_agents must be positive");
+    if ((int64_t)num_envs * num_agents > (int64_t)MARL_REWARD_EVENTS_NOALLOC_MAX_ROWS)
+        return set_error(MARL_ERR_INVALID, "marl_reward_events_noalloc handles at most " +
+                                               std::to_string(MARL_REWARD_EVENTS_NOALLOC_MAX_ROWS) +
+                                               " rows per call (num_envs * num_agents); use marl_reward_events with a workspace");
+    if (((uintptr_t)d_totals & 7u) != 0 || ((uintptr_t)d_first_rows & 7u) != 0 || ((uintptr_t)d_rewards & 3u) != 0)
+        return set_error(MARL_ERR_INVALID, "d_totals and d_first_rows must be 8-byte aligned, d_rewards 4-byte aligned");
+    if (reward_event_chunks(num_envs * num_agents) > EVENT_SCRATCH_CHUNKS)
+        return set_error(MARL_ERR_INVALID, "row count needs more partial sums than the static scratch holds");
+    uint64_t* partial = nullptr;
+    const int rc = scratch_for_current_device(&partial);
+    if (rc != MARL_OK) return rc;
+    // every chunk sum the finishing pass reads is written by the first pass of the same call:
+    // nothing in the scratch has to start at zero
+    hipError_t e = launch_reward_events(d_rewards, num_envs, num_agents, partial, d_totals, d_first_rows,
+                                        reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return set_error(MARL_ERR_HIP, std::string("reward event kernel launch: ") + hipGetErrorString(e));
+    return MARL_OK;
+}
+
