@@ -3,12 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one vectorised env.step (dynamics + featurize + auto-reset) over the
-per-GPU batch of BASELINE.json's configs[1]: overcooked_cramped_room_v0, 2 agents,
-65,536 envs, global_obs, uniform random actions (pre-generated on the device).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank steps its own 65,536
-envs (weak scaling; env RNG keys are offset by rank so the job equals one big env batch);
-there is no data-path collective.  Rank 0 prints one JSON line.
+A "step" is one vectorised env.step (dynamics + featurize + auto-reset, one kernel launch) over
+the per-GPU batch of BASELINE.json's configs[1]: overcooked_cramped_room_v0, 2 agents, 65,536
+envs, global_obs, uniform random actions (pre-generated on the device).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank steps its own 65,536 envs (weak scaling; env
+RNG keys are offset by rank so the job equals one big env batch); there is no data-path
+collective.  Rank 0 prints one JSON line.
+
+What is timed, and what the extra objects in the line mean:
+  * the timed K steps write every step's observation rows into their own tensor of a ring of 32
+    (3.4 GB), as a rollout store keeps them: the rows have to drain to HBM, and `value`, `roofline`
+    are this HBM-bound regime;
+  * `llc_resident`: the same launches alternating between TWO observation tensors (212 MB), which
+    stay in the 256 MiB last-level cache and are overwritten before they ever reach HBM: faster,
+    but a cache number, labelled as such;
+  * `step_many`: the multi-step launch (marl_env_step_many, 32 steps per launch, usable when the
+    actions are known up front as they are here), rows kept in the same ring: HBM regime;
+  * `policy_driven`: actions sampled every step from the reference-shaped fp32 MLP;
+  * `peak_measured`: what a plain device fill / copy of the same ring reaches in this run;
+  * `cpu_baseline`: the CPU restatement (oracle) on the host's cores, a bounded sample.
 """
 import argparse
 import json
@@ -29,13 +42,28 @@ def algorithmic_bytes_per_agent_step(D, state_words, A, action_bytes):
     return 4 * D + 4 + 1 + 1 + action_bytes + 2 * (4 * state_words) / A
 
 
-def cpu_baseline(layout_rows, A, feature, E, seed, threads):
+def host_threads():
+    """Threads for the CPU baseline: every host core this process may use.  os.cpu_count() is the
+    whole machine; a GPU box hands each job a share of it (scheduler affinity and the
+    OMP_NUM_THREADS it exports), and more threads than that share only time-slice."""
+    total = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = total
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = min(total, affinity, share) if share > 0 else min(total, affinity)
+    return max(threads, 1), total, affinity, share
+
+
+def cpu_baseline(layout_rows, A, feature, E, seed):
     """Time the CPU oracle (plain-C restatement, OpenMP over envs) on a bounded sample of the
     same workload.  Reported as a baseline only."""
     import numpy as np
 
     import oracle
 
+    threads, total, affinity, share = host_threads()
     oracle.build()
     env = oracle.OracleVecEnv(layout_rows, A, feature, max_steps=1000, num_envs=E, seed=seed, nthreads=threads)
     env.reset()
@@ -55,50 +83,90 @@ def cpu_baseline(layout_rows, A, feature, E, seed, threads):
         "unit": "agent-steps/s",
         "cores": threads,
         "kind": "port",
+        "host": {"os_cpu_count": total, "sched_affinity": affinity, "OMP_NUM_THREADS": share or None},
         "sample": f"{steps} steps x {E} envs x {A} agents, same layout/features/actions distribution, "
-                  f"CPU restatement (not cogrid), {dt:.1f} s",
+                  f"CPU restatement (not cogrid) on {threads} OpenMP threads = every core this job may use, {dt:.1f} s",
     }
 
 
-def rows_kept_leg(env, actions, rew, term, trunc, N, D, B, ring=32, steps=512):
-    """The same launches when every step's rows are kept (a rollout store) instead of being
-    overwritten two steps later: the rows then have to drain to HBM, whereas two alternating
-    buffers of the headline size stay in the 256 MiB last-level cache.  Reported next to the
-    headline so that both regimes are on record; `step_many` is the multi-step launch
-    (marl_env_step_many, 32 steps per launch) writing the same rows."""
-    import torch
-
-    dev = rew.device
-    ring = int(max(4, min(ring, (8 << 30) // (N * D * 4))))  # at most 8 GB of rows
-    store = torch.empty((ring, N, D), dtype=torch.float32, device=dev)
-    R = actions.shape[0]
-    for i in range(2 * ring):
-        env.step_into(actions[i % R], store[i % ring], rew, term, trunc)
+def timed(fn, count, dev):
+    """`count` calls of fn(i) between two HIP events on the current (launch) stream; us per call"""
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     ev0.record()
-    for i in range(steps):
-        env.step_into(actions[i % R], store[i % ring], rew, term, trunc)
+    for i in range(count):
+        fn(i)
     ev1.record()
-    torch.cuda.synchronize()
-    us = ev0.elapsed_time(ev1) * 1e3 / steps
-    out = {"obs_ring": ring, "us_per_launch": us, "value": N / us * 1e6, "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
+    torch.cuda.synchronize(dev)
+    return ev0.elapsed_time(ev1) * 1e3 / count
+
+
+def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
+    """Everything in the line beyond the timed region (single GPU only)."""
+    out = {}
+    R, ring = actions.shape[0], store.shape[0]
+    frac = lambda us: N * B / us / 1e3 / HBM_PEAK_GBS  # noqa: E731
+
+    # two alternating tensors: the rows never have to leave the last-level cache
+    for i in range(64):
+        env.step_into(actions[i % R], store[i % 2], rew, term, trunc)
+    us = timed(lambda i: env.step_into(actions[i % R], store[i % 2], rew, term, trunc), 1024, dev)
+    out["llc_resident"] = {
+        "regime": "obs_ring=2: 212 MB of rows stay in the 256 MiB last-level cache and are overwritten there; "
+                  "cache-resident store rate, NOT HBM bandwidth",
+        "bound": "llc", "us_per_launch": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
+        "frac_of_hbm_spec": frac(us)}
+
+    # the multi-step launch, rows kept
     if (N * D) % 4 == 0 and R >= ring:
         rew_k = torch.empty((ring, N), dtype=torch.float32, device=dev)
         te_k = torch.empty((ring, N), dtype=torch.bool, device=dev)
         tr_k = torch.empty_like(te_k)
         acts_k = actions[:ring].contiguous()
-        reps = max(steps // ring, 2)
         env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(reps):
-            env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
-        ev1.record()
-        torch.cuda.synchronize()
-        us_m = ev0.elapsed_time(ev1) * 1e3 / (reps * ring)
-        out["step_many"] = {"steps_per_launch": ring, "us_per_step": us_m, "value": N / us_m * 1e6,
-                            "frac": N * B / us_m / 1e3 / HBM_PEAK_GBS}
+        reps = 16
+        us_m = timed(lambda i: env.step_many_into(acts_k, store, rew_k, te_k, tr_k), reps, dev) / ring
+        out["step_many"] = {
+            "regime": f"marl_env_step_many, {ring} steps per launch, every step's rows kept (obs_ring={ring}): HBM",
+            "bound": "hbm", "steps_per_launch": ring, "us_per_step": us_m, "value": N / us_m * 1e6,
+            "achieved": N * B / us_m / 1e3, "unit": "GB/s", "frac": frac(us_m)}
+        del rew_k, te_k, tr_k
+
+    # what plain device writes / copies of the same memory reach in this run
+    flat = store.view(-1)
+    for _ in range(2):
+        flat.fill_(1.0)
+    us_fill = timed(lambda i: flat.fill_(float(i)), 8, dev)
+    half = flat.numel() // 2
+    a, b = flat[:half], flat[half:2 * half]
+    b.copy_(a)
+    us_copy = timed(lambda i: b.copy_(a), 8, dev)
+    out["peak_measured"] = {
+        "fill_GBps": flat.numel() * 4 / us_fill / 1e3, "copy_GBps": 2 * half * 4 / us_copy / 1e3,
+        "what": f"torch fill_ of the {flat.numel() * 4 / 1e9:.1f} GB ring (write only) and a copy of one half onto the "
+                "other (read + write bytes counted), this run"}
+
+    # policy-driven rollout: MLP forward + sample + step, the policy reading what the step wrote
+    from marl_amd.policy import Agent
+
+    torch.manual_seed(1)
+    policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
+                   build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
+    policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
+    env.reset(out=store[0])
+
+    def pstep(i):
+        with torch.no_grad():
+            act, _, _, _ = policy.get_action_and_value(store[i % ring])
+        env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
+
+    for i in range(16):
+        pstep(i)
+    us_p = timed(lambda i: pstep(16 + i), 128, dev)
+    out["policy_driven"] = {
+        "metric": "env agent-steps/sec (policy-driven rollout: fp32 MLP forward + sample + fused step+featurize)",
+        "value": N / us_p * 1e6, "unit": "agent-steps/s", "ms_per_step": us_p / 1e3, "steps": 128,
+        "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs), fused categorical sampling; rows kept"}
     return out
 
 
@@ -114,15 +182,15 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rows-kept", action="store_true",
-                    help="skip the extra leg that times the kept-rows regime (profiling runs: keeps the traced launches uniform)")
-    ap.add_argument("--obs-ring", type=int, default=2,
-                    help="observation buffers the steps cycle through (2: the next step overwrites the rows the consumer "
-                         "has just read, they never have to leave the last-level cache; 128: every step's rows are kept "
-                         "like in a rollout store and drain to HBM)")
+    ap.add_argument("--no-extra-legs", "--no-rows-kept", dest="no_extra_legs", action="store_true",
+                    help="only the timed region (profiling runs: keeps the traced launches uniform)")
+    ap.add_argument("--obs-ring", type=int, default=32,
+                    help="observation tensors the timed steps cycle through (32: every step's rows are kept like in a "
+                         "rollout store and drain to HBM; 2: the next step overwrites the rows the consumer has just "
+                         "read, they never leave the last-level cache)")
     ap.add_argument("--mode", choices=["random", "policy"], default="random",
-                    help="random: pre-generated uniform actions (headline); policy: actions sampled from the "
-                         "reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm) every step")
+                    help="random: pre-generated uniform actions (headline); policy: the timed steps sample their actions "
+                         "from the reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,13 +203,15 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    group = None
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run, also with one rank
         import torch.distributed as dist
 
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
         else:
             dist.init_process_group(backend)
+        group = backend
 
     from marl_amd.env import BatchedOvercookedVecEnv
     from marl_amd.layouts import get_layout
@@ -154,12 +224,12 @@ def main():
     R = 32  # distinct pre-generated action batches, cycled
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     actions = torch.randint(0, 7, (R, N), dtype=torch.int64, device=dev, generator=gen)
-    RING = max(2, args.obs_ring)
-    obs = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(RING)]
+    RING = int(max(2, min(args.obs_ring, (8 << 30) // (N * D * 4))))  # at most 8 GB of rows
+    store = torch.empty((RING, N, D), dtype=torch.float32, device=dev)
     rew = torch.empty(N, dtype=torch.float32, device=dev)
     term = torch.empty(N, dtype=torch.bool, device=dev)
     trunc = torch.empty(N, dtype=torch.bool, device=dev)
-    env.reset(out=obs[0])
+    env.reset(out=store[0])
 
     policy = None
     if args.mode == "policy":
@@ -167,23 +237,24 @@ def main():
 
         torch.manual_seed(1)
         policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
-                       build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
-        policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
+                       build_centralised=False).to(dev)
+        policy.use_fused_sampling(1234, row_index_base=rank * N)
 
     def eager(i):
+        # step i reads (policy mode) the rows in slot i and writes slot i + 1; slot 0 holds the reset's rows
         if policy is None:
-            env.step_into(actions[i % R], obs[i % RING], rew, term, trunc)
+            env.step_into(actions[i % R], store[(i + 1) % RING], rew, term, trunc)
         else:
             with torch.no_grad():
-                act, _, _, _ = policy.get_action_and_value(obs[(i - 1) % RING])
-            env.step_into(act, obs[i % RING], rew, term, trunc)
+                act, _, _, _ = policy.get_action_and_value(store[i % RING])
+            env.step_into(act, store[(i + 1) % RING], rew, term, trunc)
 
     for i in range(args.warmup):
         eager(i)
     torch.cuda.synchronize()
 
     graph = None
-    if args.graph and not args.no_graph and args.steps >= R:
+    if args.graph and not args.no_graph and args.steps >= R and RING in (2, 4, 8, 16, 32):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for i in range(R):
@@ -213,7 +284,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
 
-    if world > 1:
+    if group is not None:
         tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = tt.tolist()
@@ -222,9 +293,10 @@ def main():
         B = algorithmic_bytes_per_agent_step(D, env.state_words, A, actions.element_size())
         launch_s = dev_ms * 1e-3 / args.steps  # device-side time per launch, HIP events on the launch stream
         achieved = N * B / launch_s / 1e9
+        kept = RING * N * D * 4 > (256 << 20)  # more rows alive than the last-level cache holds
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        key = f"{args.layout}/{A}/{args.feature}/{E}"
+        key = f"{args.layout}/{A}/{args.feature}/{E}/" + ("kept" if kept else "llc")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(key)
@@ -244,24 +316,35 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.layout}, {A} agents, {E} envs per GPU, {args.feature} (D={D}), "
                                    + ("uniform random int64 actions" if policy is None else "actions sampled from the fp32 MLP policy")
-                                   + ", auto-reset at t=1000",
-                       "launch": "hipGraph of 32 steps" if graph is not None else "eager"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   + ", auto-reset at t=1000, one launch per step, "
+                                   + (f"every step's rows kept (ring of {RING} observation tensors, {RING * N * D * 4 / 1e9:.1f} GB)"
+                                      if kept else f"{RING} alternating observation tensors (cache resident)"),
+                       "launch": "hipGraph of 32 steps" if graph is not None else "eager",
+                       "obs_ring": RING, "process_group": group},
+            "roofline": {"bound": "hbm" if kept else "llc",
+                         "regime": ("rows kept: they drain to HBM while they are written" if kept else
+                                    "rows overwritten inside the 256 MiB last-level cache: a cache number, not HBM bandwidth"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch) of an earlier "
+                         "run of this command, not measured in this run",
                          "bytes_per_agent_step": B, "kernel": f"env_kernel<{A} agents, {args.feature}> (step+featurize)",
                          "us_per_launch": launch_s * 1e6},
         }
-        out["config"]["obs_ring"] = RING
         if policy is not None:
             # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
             out["roofline"] = None
-        elif world == 1 and RING == 2 and not args.graph and not args.no_rows_kept:
-            out["rows_kept"] = rows_kept_leg(env, actions, rew, term, trunc, N, D, B)
+        if world == 1 and policy is None and not args.no_extra_legs:
+            legs = extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A)
+            pm = legs.pop("peak_measured")
+            out["roofline"]["peak_measured"] = pm
+            out["roofline"]["frac_of_measured_fill"] = achieved / pm["fill_GBps"]
+            out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234, threads)
+            out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

@@ -13,6 +13,13 @@
  * per-step calls; marl_env_create / marl_env_destroy allocate and free the small per-layout
  * lookup tables.  Every function returns 0 on success and a negative code on failure;
  * marl_last_error() describes the last failure on the calling thread.
+ *
+ * Threads: different env handles may be created, stepped and destroyed from different host
+ * threads at the same time (the library's own shared bookkeeping is locked).  One handle belongs to
+ * one host thread and one stream at a time: its state buffer is updated in place and
+ * marl_env_set_auto_reset changes the handle without locking.  A handle belongs to the HIP
+ * device that was current when it was created; every call on it must be made with that device
+ * current (MARL_ERR_INVALID otherwise).
  */
 #ifndef MARL_AMD_H
 #define MARL_AMD_H

@@ -36,7 +36,7 @@ class CMAPPO(MAPPO):
 
     def compute_gae(self, rewards, dones, values, next_values, want_returns=False):
         reward_mean = None
-        if dist_utils.world_size() > 1:
+        if dist_utils.collectives_active():
             sums = dist_utils.all_reduce_sum_(row_sums(rewards))
             rows = torch.tensor([rewards.shape[1]], dtype=torch.float64, device=rewards.device)
             dist_utils.all_reduce_sum_(rows)

@@ -50,7 +50,7 @@ class MAPPO:
         # launch-bound; single rank only (the gradient all-reduce sits in the middle of the step)
         small = batch_size // max(num_mini_batches, 1) <= 65536
         self._graph_update = (graph_update == "on" or (graph_update == "auto" and small)) \
-            and dist_utils.world_size() == 1 and self.device.type == "cuda" and optimzer is not None
+            and not dist_utils.collectives_active() and self.device.type == "cuda" and optimzer is not None
         self._g = None
         # loss + head gradients from one HIP pass (marl_amd.ppo_loss) instead of ~70 autograd ops:
         # the decentralised loss on the GPU only (CMAPPO's value loss has another form)

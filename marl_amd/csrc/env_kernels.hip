@@ -37,6 +37,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "oc_common.h"
@@ -840,6 +841,7 @@ __device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, cons
 // ---------------------------------------------------------------------------------------
 #define OC_KERNEL_NAME env_kernel
 #define OC_MANY 0
+#define OC_IMG 0
 #include "env_kernel_body.inc"
 #undef OC_KERNEL_NAME
 #undef OC_MANY
@@ -848,6 +850,16 @@ __device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, cons
 #include "env_kernel_body.inc"
 #undef OC_KERNEL_NAME
 #undef OC_MANY
+#undef OC_IMG
+#ifdef OC_SPLIT  // diagnostic build only: the split form measured slower (profiles/r02/split_form.txt)
+#define OC_KERNEL_NAME env_kernel_img
+#define OC_MANY 0
+#define OC_IMG 1
+#include "env_kernel_body.inc"
+#undef OC_KERNEL_NAME
+#undef OC_MANY
+#undef OC_IMG
+#endif
 
 // ---------------------------------------------------------------------------------------
 // dispatch
@@ -864,21 +876,38 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     constexpr int RPW = 64 / lanes_per_env(A) * A;  // rows per wave
     while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * RPW * G::D > 64 * 1024) waves >>= 1;
     const size_t lds = (size_t)P.tab_bytes + (size_t)waves * RPW * G::D;
-    static size_t configured[64] = {0};  // per instantiation and device
+    // dynamic-LDS limit already granted to this instantiation's kernels, per device; host threads
+    // that step different handles of one family at the same time meet here
+    static size_t configured[64] = {0};
+    static std::mutex configured_mutex;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::unique_lock<std::mutex> configured_lock(configured_mutex);
     if (lds > configured[dev]) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<A, FEAT, NIW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel_many<A, FEAT, NIW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef OC_SPLIT
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel_img<A, FEAT, NIW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
         if (err != hipSuccess) return err;
         configured[dev] = lds;
     }
+    configured_lock.unlock();
     const size_t N = (size_t)P.E * A;
     const size_t rows_per_block = (size_t)waves * RPW;
     const unsigned grid = (unsigned)((N + rows_per_block - 1) / rows_per_block);
+#ifdef OC_SPLIT
+    if (P.img_out) {
+        hipLaunchKernelGGL((env_kernel_img<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
+                           actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
+        return hipGetLastError();
+    }
+#endif
     if (P.nsteps > 1 && (mode & 0xFF) == 0)
         hipLaunchKernelGGL((env_kernel_many<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
                            actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);

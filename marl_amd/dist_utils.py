@@ -11,13 +11,19 @@ import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """MARL_AMD_FORCE_COLLECTIVES=1: issue every collective even in a one-rank group, so that a single
+    GPU exercises the RCCL code path end to end (tests)."""
+    return os.environ.get("MARL_AMD_FORCE_COLLECTIVES") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* if the job was
     launched by torch.distributed.run; returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (_forced() and "RANK" in os.environ)) and not dist.is_initialized():
         if backend is None:
             # MARL_AMD_DIST_BACKEND=gloo lets several ranks share one GPU (tests); RCCL needs one GPU per rank
             backend = os.environ.get("MARL_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -37,24 +43,72 @@ def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def collectives_active():
+    """True when collectives have to be issued: more than one rank, or a one-rank group with
+    MARL_AMD_FORCE_COLLECTIVES=1."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _forced()
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
+def drain_needed():
+    """Whether the launch stream has to be drained before a collective that follows a hipGraph
+    replay.  MARL_AMD_DRAIN = auto (default: only for the gloo backend) | always | never."""
+    mode = os.environ.get("MARL_AMD_DRAIN", "auto")
+    if mode == "always":
+        return True
+    if mode == "never":
+        return False
+    return backend_name() == "gloo"
+
+
+_trace_count = 0
+
+
+def _all_reduce(t):
+    """dist.all_reduce(SUM); MARL_AMD_DIST_TRACE=1 prints entry and exit per rank (diagnosis of stalls)."""
+    global _trace_count
+    if os.environ.get("MARL_AMD_DIST_TRACE") == "1":
+        import sys
+
+        _trace_count += 1
+        print(f"[rank {get_rank()}] all_reduce #{_trace_count} {tuple(t.shape)} {t.dtype} on {t.device}: enter",
+              file=sys.stderr, flush=True)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        print(f"[rank {get_rank()}] all_reduce #{_trace_count}: returned", file=sys.stderr, flush=True)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class FlatGradAllReducer:
     """Averages gradients across ranks with ONE collective per call: the gradients that exist
     are packed into a persistent flat buffer (~0.95 MB fp32 for the 202-input policy),
     all-reduced, and unpacked in place.  At this size the collective is latency-bound, so one
-    call beats one per parameter.  Parameters without a gradient (the centralised critic is
-    never trained, model.py:56-60, and is as wide as D * A * E) take no part: every rank runs
-    the same graph, so the set is the same everywhere."""
+    call beats one per parameter.  Packing and unpacking are one multi-tensor launch each
+    (``torch._foreach_copy_`` between the gradients and same-shaped views of the flat buffer): two
+    launches around the collective whatever the number of parameters.  (Making the ``.grad``s
+    themselves views of the buffer would save those two but cost more: autograd then accumulates
+    into the existing gradient with one add per parameter and the buffer needs a zero-fill per
+    step.)  Parameters without a gradient (the centralised critic is never trained,
+    model.py:56-60, and is as wide as D * A * E) take no part: every rank runs the same graph,
+    so the set is the same everywhere."""
 
     def __init__(self, parameters):
         self.params = [p for p in parameters if p.requires_grad]
         self.active = None
         self.flat = None
+        self.views = None
+        self.calls = 0  # collectives issued (tests)
 
     @torch.no_grad()
     def __call__(self):
-        w = world_size()
-        if w == 1:
+        if not collectives_active():
             return
+        w = world_size()
         active = [k for k, p in enumerate(self.params) if p.grad is not None]
         if not active:
             return
@@ -62,29 +116,29 @@ class FlatGradAllReducer:
             ref = self.params[active[0]]
             n = sum(self.params[k].numel() for k in active)
             self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+            self.views, off = [], 0
+            for k in active:
+                p = self.params[k]
+                self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
             self.active = active
-        off = 0
-        for k in active:
-            g = self.params[k].grad
-            self.flat[off:off + g.numel()].copy_(g.reshape(-1))
-            off += g.numel()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(w)
-        off = 0
-        for k in active:
-            g = self.params[k].grad
-            g.copy_(self.flat[off:off + g.numel()].reshape(g.shape))
-            off += g.numel()
+        grads = [self.params[k].grad for k in active]
+        torch._foreach_copy_(self.views, grads)
+        _all_reduce(self.flat)
+        self.calls += 1
+        if w > 1:
+            self.flat.div_(w)
+        torch._foreach_copy_(grads, self.views)
 
 
 def all_reduce_sum_(t):
-    if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if collectives_active():
+        _all_reduce(t)
     return t
 
 
 def broadcast_parameters(module, src=0):
-    if world_size() > 1:
+    if collectives_active():
         for p in module.parameters():
             dist.broadcast(p.data, src)
         for b in module.buffers():

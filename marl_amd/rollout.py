@@ -170,7 +170,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         # A collective's stream waits on an event recorded behind the graph launch; with ranks
         # sharing work through gloo that wait was seen never to return on ROCm 7.2 unless the
         # launch stream had drained first.  Once per rollout / per episode: no measurable cost.
-        if use_graphs and dist_utils.world_size() > 1:
+        if use_graphs and dist_utils.collectives_active() and dist_utils.drain_needed():
             torch.cuda.current_stream(device).synchronize()
 
     rng = range(num_update)
@@ -200,7 +200,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 totals, first_rows = stats.raw()
                 tot_all = totals.to(torch.float64)
                 drain_before_collective()
-                if dist_utils.world_size() > 1:
+                if dist_utils.collectives_active():
                     dist_utils.all_reduce_sum_(tot_all)
                     tot_all /= dist_utils.world_size()
                 t = tot_all.tolist()  # the one host sync per episode

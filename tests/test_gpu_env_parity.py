@@ -397,3 +397,44 @@ def test_many_steps_in_one_launch(layout, A, feature, E):
         assert torch.equal(one.state, many.state)
     with pytest.raises(ValueError):
         many.step_many_into(acts[:, :-1], obs2, rew2, te2, tr2)
+
+
+def test_two_host_threads_step_their_own_handles(oracle_mod):
+    """Different env handles of one kernel family, created and stepped at the same time from two
+    host threads on their own streams (the library's shared bookkeeping is locked): both match
+    the oracle."""
+    import threading
+
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+    from marl_amd.layouts import get_layout
+
+    rows = get_layout("overcooked_cramped_room_v0")
+    errors = []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            rng = np.random.default_rng(seed)
+            with torch.cuda.stream(stream):
+                for rep in range(3):
+                    E = 64 + 32 * rep
+                    gpu = BatchedOvercookedVecEnv(rows, 2, "global_obs", E, max_steps=15, seed=seed + rep)
+                    ora = oracle_mod.OracleVecEnv(rows, 2, "global_obs", max_steps=15, num_envs=E, seed=seed + rep)
+                    o, _ = gpu.reset()
+                    assert np.array_equal(o[OBS_KEY].cpu().numpy(), ora.reset())
+                    for _ in range(20):
+                        act = rng.integers(0, 7, size=E * 2)
+                        o, r, _, tr, _ = gpu.step(torch.from_numpy(act))
+                        oo, ro, _, tro = ora.step(act)
+                        assert np.array_equal(o[OBS_KEY].cpu().numpy(), oo)
+                        assert np.array_equal(r.cpu().numpy(), ro) and np.array_equal(tr.cpu().numpy(), tro)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in (100, 200)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
