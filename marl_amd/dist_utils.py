@@ -55,22 +55,30 @@ def backend_name():
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
-def drain_needed():
-    """Whether the launch stream has to be drained before a collective that follows a hipGraph
-    replay.  MARL_AMD_DRAIN = auto (default: only for the gloo backend) | always | never."""
-    mode = os.environ.get("MARL_AMD_DRAIN", "auto")
-    if mode == "always":
-        return True
-    if mode == "never":
-        return False
-    return backend_name() == "gloo"
-
-
 _trace_count = 0
 
 
+def _reduce(t):
+    """SUM over ranks, in place.  RCCL reduces device memory on its own stream, ordered behind the
+    caller's stream by an event; nothing waits on the host.  gloo cannot reduce device memory: given a
+    device tensor it stages it through the host itself, from a worker thread that waits on a side
+    stream ordered behind the caller's stream, while the calling thread blocks until that worker is
+    done.  On ROCm 7.2 that wait never returned once the caller's stream had replayed hipGraphs
+    (two ranks sharing a GPU, second graph-replayed rollout: both ranks stuck in the same
+    all_reduce, worker thread in its stream wait; profiles/diag/two_rank_train.sh), whereas a wait
+    on the caller's own stream from the calling thread always returned.  So for gloo the staging
+    is done here, on the caller's stream: copy to the host (which waits for that stream), reduce
+    host memory, copy back."""
+    if t.is_cuda and backend_name() == "gloo" and os.environ.get("MARL_AMD_GLOO_DEVICE_TENSORS") != "1":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def _all_reduce(t):
-    """dist.all_reduce(SUM); MARL_AMD_DIST_TRACE=1 prints entry and exit per rank (diagnosis of stalls)."""
+    """_reduce; MARL_AMD_DIST_TRACE=1 prints entry and exit per rank (diagnosis of stalls)."""
     global _trace_count
     if os.environ.get("MARL_AMD_DIST_TRACE") == "1":
         import sys
@@ -78,10 +86,10 @@ def _all_reduce(t):
         _trace_count += 1
         print(f"[rank {get_rank()}] all_reduce #{_trace_count} {tuple(t.shape)} {t.dtype} on {t.device}: enter",
               file=sys.stderr, flush=True)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _reduce(t)
         print(f"[rank {get_rank()}] all_reduce #{_trace_count}: returned", file=sys.stderr, flush=True)
         return
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _reduce(t)
 
 
 class FlatGradAllReducer:

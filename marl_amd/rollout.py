@@ -86,8 +86,8 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     episode_span = max_steps + 1  # driver steps per episode: the reference notices an episode's end one step late
     # "auto": replay the rollout from hipGraphs when it is launch-bound (few rows per launch)
     graph_mode = getattr(args, "graph_rollout", "off")
-    # and the job is a single rank ("on" forces it; multi-rank replay is exercised over gloo only)
-    use_graphs = graph_mode == "on" or (graph_mode == "auto" and N <= 16384 and dist_utils.world_size() == 1)
+    # (collectives are issued between graph replays, never captured)
+    use_graphs = graph_mode == "on" or (graph_mode == "auto" and N <= 16384)
 
     episodes_reward, deliveries, platings, pottings = [], [], [], []
     all_env = {"episode_return_all_envs": [], "deliveries_all_envs": [], "platings_all_envs": [],
@@ -166,13 +166,6 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         buf.ptr = (first + count) % buf.max_size
         buf.size = min(first + count, buf.max_size)
 
-    def drain_before_collective():
-        # A collective's stream waits on an event recorded behind the graph launch; with ranks
-        # sharing work through gloo that wait was seen never to return on ROCm 7.2 unless the
-        # launch stream had drained first.  Once per rollout / per episode: no measurable cost.
-        if use_graphs and dist_utils.collectives_active() and dist_utils.drain_needed():
-            torch.cuda.current_stream(device).synchronize()
-
     rng = range(num_update)
     if progress:
         try:
@@ -199,7 +192,6 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 env.reset(out=slot(step))
                 totals, first_rows = stats.raw()
                 tot_all = totals.to(torch.float64)
-                drain_before_collective()
                 if dist_utils.collectives_active():
                     dist_utils.all_reduce_sum_(tot_all)
                     tot_all /= dist_utils.world_size()
@@ -225,7 +217,6 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
                 torch.logical_or(term_rows[:-1], trunc_rows[:-1], out=buf.dones_buff[1:])
             torch.logical_or(term_rows[-1], trunc_rows[-1], out=dones)
             agent.end_direct_rollout(act_rows)
-        drain_before_collective()
         agent.update(carry)
         # the stored rows restart at 0: the carried observation (and its done flag) becomes row 0
         buf.obs_slot(0).copy_(carry)

@@ -74,7 +74,7 @@ def build_parser():
     p.add_argument("--fused-loss", choices=["on", "off"], default="on",
                    help="decentralised MAPPO on the GPU: loss and head gradients from one HIP pass instead of autograd's small ops")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
-                   help="replay rollout steps from hipGraphs (auto: single rank and at most 16,384 rows per launch)")
+                   help="replay rollout steps from hipGraphs (auto: at most 16,384 rows per launch)")
     return p
 
 

@@ -32,7 +32,7 @@ def _launch(script_and_args, extra_env, timeout=240):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("algorithm,graph_rollout", [("mappo", "on"), ("cmappo", "off")])
+@pytest.mark.parametrize("algorithm,graph_rollout", [("mappo", "on"), ("cmappo", "on"), ("cmappo", "off")])
 def test_training_collectives_run_over_rccl(tmp_path, algorithm, graph_rollout):
     script = tmp_path / "run.py"
     script.write_text(
