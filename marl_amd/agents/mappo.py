@@ -113,7 +113,7 @@ class MAPPO:
 
     # ------------------------------------------------------------------ update
     def _minibatch_step(self, mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target):
-        """agents/MAPPO.py:167-209 for one minibatch; returns the six logged statistics."""
+        """agents/MAPPO.py:167-209 for one minibatch; returns the seven logged statistics."""
         if self._fused_loss:
             from ..ppo_loss import ppo_loss
 
@@ -123,9 +123,9 @@ class MAPPO:
             self.optimizer.zero_grad()
             loss.backward()
             self._reducer()
-            torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+            norm = torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
             self.optimizer.step()
-            return stats[1:]
+            return torch.cat([stats[1:], self._clipped_norm(norm).reshape(1)])
         _, newlogprob, entropy, newvalue = self.policy.get_action_and_value(b_obs[mb], b_actions_f[mb].long())
         logratio = newlogprob - b_logprobs[mb]
         ratio = logratio.exp()
@@ -139,12 +139,22 @@ class MAPPO:
         self.optimizer.zero_grad()
         loss.backward()
         self._reducer()  # RCCL: one flat all-reduce, no-op on a single rank
-        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        norm = torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
         self.optimizer.step()
 
         with torch.no_grad():
             return torch.stack([v_loss, pg_loss, entropy_loss, ((ratio - 1) - logratio).mean(), (-logratio).mean(),
-                                ((ratio - 1.0).abs() > self.clip_param).float().mean()]).double()
+                                ((ratio - 1.0).abs() > self.clip_param).float().mean(),
+                                self._clipped_norm(norm).float()]).double()
+
+    def _clipped_norm(self, total_norm):
+        """The reference logs the gradient norm AFTER clip_grad_norm_ has scaled the gradients in
+        place (agents/MAPPO.py:208,216): the norm before clipping times the factor the clip applied
+        (max_norm / (norm + 1e-6), at most 1).  Computed from clip_grad_norm_'s return value, on the
+        device, without another pass over the gradients."""
+        with torch.no_grad():
+            scale = torch.clamp(self.max_grad_norm / (total_norm + 1e-6), max=1.0)
+            return (total_norm * scale).double()
 
     def _replay_minibatch(self, mb, b_obs, b_actions_f, b_logprobs, b_advantages, b_value_target):
         """The same step replayed from a hipGraph.  Captured once, after the first eager update has
@@ -190,7 +200,7 @@ class MAPPO:
         if self.batch_size != total:
             raise ValueError(f"batch_size {self.batch_size} != stored samples {total}")
 
-        sums = torch.zeros(6, dtype=torch.float64, device=self.device)  # v, pg, ent, kl, old_kl, clipfrac
+        sums = torch.zeros(7, dtype=torch.float64, device=self.device)  # v, pg, ent, kl, old_kl, clipfrac, grad norm
         count = 0
         idx = np.arange(total)  # agents/MAPPO.py:156: shuffled in place epoch after epoch, never re-sorted
         for _ in range(self.ppo_epoch):
@@ -208,13 +218,14 @@ class MAPPO:
                 count += 1
         self.num_gradient_steps += 1
         stats = (sums / max(count, 1)).tolist()  # one sync per update
-        self.last_stats = dict(zip(("value_loss", "policy_loss", "entropy", "approx_kl", "old_approx_kl", "clipfrac"),
-                                   stats))
+        self.last_stats = dict(zip(("value_loss", "policy_loss", "entropy", "approx_kl", "old_approx_kl", "clipfrac",
+                                    "policy_grad_norm"), stats))
         if self.log and self.summary_writer is not None:
             self.summary_writer.add_scalar("charts/learning_rate", self.optimizer.param_groups[0]["lr"],
                                            self.num_gradient_steps)
             for k, v in self.last_stats.items():
-                self.summary_writer.add_scalar(f"losses/{k}", v, self.num_gradient_steps)
+                tag = "NN/policy_grad_norm" if k == "policy_grad_norm" else f"losses/{k}"  # agents/MAPPO.py:213-218
+                self.summary_writer.add_scalar(tag, v, self.num_gradient_steps)
         if self.save_path is not None and self.num_gradient_steps % 100 == 0 and dist_utils.get_rank() == 0:
             self.save_model()
         buf.reset()
@@ -225,9 +236,19 @@ class MAPPO:
         return f"{kind}_policy_{a.num_agents}_agents_{a.layout}_seed_{a.seed}.pth"
 
     def save_model(self):
+        """agents/MAPPO.py:226-231.  The reference's loader is strict (tests/test_load.py:71) and its
+        model always holds a centralised critic obs_dim * num_agents * num_envs wide (model.py:28-34).
+        A run with many envs does not build that critic here (gigabytes of never-trained weights);
+        its checkpoint then lacks the centralised_critics.* entries and loads into the reference's
+        model only with strict=False, which is said once when it is written."""
         os.makedirs(self.save_path, exist_ok=True)
         path = os.path.join(self.save_path, self.checkpoint_name())
-        torch.save(self.policy.state_dict(), path)
+        sd = self.policy.state_dict()
+        if not any(k.startswith("centralised_critics.") for k in sd) and not getattr(self, "_warned_critic", False):
+            self._warned_critic = True
+            print(f"note: {path} holds no centralised_critics.* entries (the critic is not built at this env count); "
+                  "the reference's model loads it with load_state_dict(..., strict=False)", flush=True)
+        torch.save(sd, path)
         return path
 
     def get_grad_norm(self, module):

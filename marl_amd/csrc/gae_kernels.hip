@@ -19,7 +19,10 @@ namespace oc {
 // (48.8 / 50.6 / 50.4 / 60.0 us), and storing the two outputs with the non-temporal hint takes the
 // launch from 62 us to 49 us: the 134 MB written would otherwise push the three input planes the
 // scan is still reading out of the last-level cache.
-constexpr int GAE_UNROLL = 6;
+#ifndef OC_GAE_UNROLL
+#define OC_GAE_UNROLL 6
+#endif
+constexpr int GAE_UNROLL = OC_GAE_UNROLL;
 
 __global__ void __launch_bounds__(256)
 gae_kernel(const float* __restrict__ rewards, const float* __restrict__ dones, const float* __restrict__ values,
