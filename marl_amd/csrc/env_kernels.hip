@@ -515,23 +515,14 @@ __device__ __forceinline__ uint32_t step_env_quad(EnvState<A, NIW>& s, const Lds
         });
         movers = sorted;
     } else {
-        // Fisher-Yates on the packed list, i = m-1 .. 1.  Step i (taken when i < m) is the
-        // (m-1-i)-th draw of this shuffle, so its counter value is known up front and the A-1
-        // hashes do not wait for each other; only the swaps are applied in order.
-        uint32_t jdraw[A];
+        // Fisher-Yates on the packed list, i = m-1 .. 1
         static_for<1, A>([&](auto K) {
             constexpr int k = A - K.value;  // A-1 .. 1
-            const uint32_t r = mix32(s.rng.key ^ (s.rng.ctr + (m - 1u - (uint32_t)k)));
-            jdraw[k] = __umulhi(r, (uint32_t)(k + 1));
-        });
-        static_for<1, A>([&](auto K) {
-            constexpr int k = A - K.value;
             const bool on = (uint32_t)k < m;
-            const uint32_t j = jdraw[k];
+            const uint32_t j = s.rng.below(k + 1, on);
             const uint32_t x = on ? (((movers >> (4 * k)) ^ (movers >> (4 * j))) & 15u) : 0u;
             movers ^= (x << (4 * k)) | (x << (4 * j));
         });
-        s.rng.ctr += m > 0u ? m - 1u : 0u;
     }
     // first claim wins: a lane follows its own agent only and asks the quad whether the target
     // of the agent being served is held by somebody whose place is settled
@@ -572,66 +563,35 @@ __device__ __forceinline__ uint32_t step_env_quad(EnvState<A, NIW>& s, const Lds
     // counter slot, pot, whether another agent stands in front, whether it interacts at all);
     // what depends on the running state (what lies there, holdings, pot condition) is looked up
     // by every lane for every agent in turn.
-    const bool on_me = real && my_act == (uint32_t)ACT_PICKUP_DROP;
+    const bool on_me = my_act == (uint32_t)ACT_PICKUP_DROP;
     uint32_t my_desc;
     uint32_t rew_bits;
-    uint32_t my_out;  // my agent's interaction looked up on the state before anybody interacted
     {
         const uint32_t w = sel4(nbm, pick<A>(s.dir, i));
         const uint32_t ct = nb_type(w), slot = nb_slot(w), p = nb_pot(w), nf = nb_fidx(w);
         const uint32_t rent = T.rew_entry(ct | (my_inv0 << 3) | (pot_state(prev_pots, p) << 5));
-        rew_bits = on_me ? rent : 0u;  // onion in pot | soup plated << 1 | delivery << 2
+        rew_bits = (on_me && real) ? rent : 0u;  // onion in pot | soup plated << 1 | delivery << 2
         uint32_t ahead = 0;
         static_for<0, A>([&](auto B) { ahead |= (s.f[B.value] == nf && (uint32_t)B.value != i) ? 1u : 0u; });
         // ct and ahead sit where the decision table's index wants them
         my_desc = ct | (ahead << 9) | (slot << 10) | (p << 17) | ((on_me ? 1u : 0u) << 19);
-        const uint32_t inv = pick<A>(s.inv, i);
-        const uint32_t looked = T.int_entry(ct | (item_get<NIW>(s.items, slot) << 3) | (inv << 5) |
-                                            (pot_state(s.pots, p) << 7) | (ahead << 9));
-        // new holding | item op << 2 | pot op << 4 | holding before << 6, then slot and pot as in my_desc
-        my_out = (on_me ? looked : inv) | (inv << 6) | (slot << 10) | (p << 17);
     }
-    // An agent's interaction depends on an earlier agent's only through the cell or the pot both
-    // touch.  Quads in which no two interacting agents share one take every agent's own lookup
-    // (one table read per lane, side by side); the others go through the agents one after another.
-    bool clash = false;
-    static_for<0, A>([&](auto B) {
-        const uint32_t d = quad_bcast<B.value>(my_desc);
-        const bool both = on_me && ((d >> 19) & 1u) && (uint32_t)B.value != i;
-        const bool same_slot = ((d ^ my_desc) & (127u << 10)) == 0u && ((my_desc >> 10) & 127u) != NB_NO_SLOT;
-        const bool same_pot = (d & 7u) == POT && (my_desc & 7u) == POT && ((d ^ my_desc) & (3u << 17)) == 0u;
-        clash = clash || (both && (same_slot || same_pot));
+    static_for<0, A>([&](auto AI) {
+        constexpr int a = AI.value;
+        const uint32_t dsc = quad_bcast<a>(my_desc);
+        const bool on = (dsc >> 19) & 1u;
+        const uint32_t slot = (dsc >> 10) & 127u, p = (dsc >> 17) & 3u;
+        const uint32_t lying = item_get<NIW>(s.items, slot);
+        const uint32_t inv = s.inv[a];
+        const uint32_t looked = T.int_entry((dsc & 0x207u) | (lying << 3) | (inv << 5) | (pot_state(s.pots, p) << 7));
+        const uint32_t ent = on ? looked : inv;  // new holding | item op << 2 | pot op << 4
+        const uint32_t iop = (ent >> 2) & 3u, pop = (ent >> 4) & 3u;
+        s.inv[a] = ent & 3u;
+        item_set<NIW>(s.items, slot, iop == INT_ITEM_CLEAR ? (uint32_t)NONE : inv, iop != INT_ITEM_KEEP);
+        const uint32_t pbyte = 0xFFu << (8u * p);
+        s.pots = pop == INT_POT_RESET ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
+        s.pots += pop == INT_POT_ADD ? (1u << (8u * p)) : 0u;
     });
-    if (quad_or(clash ? 1u : 0u) == 0u) {
-        static_for<0, A>([&](auto AI) {
-            constexpr int a = AI.value;
-            const uint32_t o = quad_bcast<a>(my_out);
-            const uint32_t iop = (o >> 2) & 3u, pop = (o >> 4) & 3u, inv = (o >> 6) & 3u;
-            const uint32_t slot = (o >> 10) & 127u, p = (o >> 17) & 3u;
-            s.inv[a] = o & 3u;
-            item_set<NIW>(s.items, slot, iop == INT_ITEM_CLEAR ? (uint32_t)NONE : inv, iop != INT_ITEM_KEEP);
-            const uint32_t pbyte = 0xFFu << (8u * p);
-            s.pots = pop == INT_POT_RESET ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
-            s.pots += pop == INT_POT_ADD ? (1u << (8u * p)) : 0u;
-        });
-    } else {
-        static_for<0, A>([&](auto AI) {
-            constexpr int a = AI.value;
-            const uint32_t dsc = quad_bcast<a>(my_desc);
-            const bool on = (dsc >> 19) & 1u;
-            const uint32_t slot = (dsc >> 10) & 127u, p = (dsc >> 17) & 3u;
-            const uint32_t lying = item_get<NIW>(s.items, slot);
-            const uint32_t inv = s.inv[a];
-            const uint32_t looked = T.int_entry((dsc & 0x207u) | (lying << 3) | (inv << 5) | (pot_state(s.pots, p) << 7));
-            const uint32_t ent = on ? looked : inv;  // new holding | item op << 2 | pot op << 4
-            const uint32_t iop = (ent >> 2) & 3u, pop = (ent >> 4) & 3u;
-            s.inv[a] = ent & 3u;
-            item_set<NIW>(s.items, slot, iop == INT_ITEM_CLEAR ? (uint32_t)NONE : inv, iop != INT_ITEM_KEEP);
-            const uint32_t pbyte = 0xFFu << (8u * p);
-            s.pots = pop == INT_POT_RESET ? ((s.pots & ~pbyte) | ((uint32_t)(COOK_TIME << 2) << (8u * p))) : s.pots;
-            s.pots += pop == INT_POT_ADD ? (1u << (8u * p)) : 0u;
-        });
-    }
     return (rew_bits & 3u) | (quad_sum((rew_bits >> 2) & 1u) << 2);
 }
 
