@@ -42,6 +42,10 @@
 
 #include "oc_common.h"
 
+#ifndef OC_DEFER_SMALL_STORES
+#define OC_DEFER_SMALL_STORES 1  // three and four agents: rewards / flags / state stored after the row stream
+#endif
+
 // Cache policy of the observation stores (buffer-instruction aux bits on gfx950: 1 = sc0,
 // 2 = nt, 16 = sc1).  sc1 = write-through: what a launch writes does not stay dirty in the
 // XCD L2s, so the end-of-kernel write-back has nothing left to flush.  Measured per launch on
@@ -225,6 +229,24 @@ __device__ __forceinline__ void store_state(const EnvState<A, NIW>& s, uint32_t*
         wt_store(p + (size_t)(3 + k) * stride, aw);
     });
     static_for<0, NIW>([&](auto K) { wt_store(p + (size_t)(3 + (A + 1) / 2 + K.value) * stride, s.items[K.value]); });
+}
+
+// the same in two halves, for a caller that stores later than it packs
+template <int A, int NIW>
+__device__ __forceinline__ void pack_state(uint32_t (&raw)[3 + (A + 1) / 2 + NIW], const EnvState<A, NIW>& s) {
+    raw[0] = s.t; raw[1] = s.rng.ctr; raw[2] = s.pots;
+    static_for<0, (A + 1) / 2>([&](auto K) {
+        constexpr int k = K.value;
+        uint32_t aw = s.f[2 * k] | (s.dir[2 * k] << 8) | (s.inv[2 * k] << 10);
+        if constexpr (2 * k + 1 < A) aw |= (s.f[2 * k + 1] << 16) | (s.dir[2 * k + 1] << 24) | (s.inv[2 * k + 1] << 26);
+        raw[3 + k] = aw;
+    });
+    static_for<0, NIW>([&](auto K) { raw[3 + (A + 1) / 2 + K.value] = s.items[K.value]; });
+}
+template <int A, int NIW>
+__device__ __forceinline__ void store_raw(const uint32_t (&raw)[3 + (A + 1) / 2 + NIW], uint32_t* __restrict__ st, int E, int e) {
+    uint32_t* p = st + e;
+    static_for<0, 3 + (A + 1) / 2 + NIW>([&](auto K) { wt_store(p + (size_t)K.value * (size_t)E, raw[K.value]); });
 }
 
 // ---------------------------------------------------------------------------------------
