@@ -3,10 +3,13 @@
 ReLU), ``actor`` (256 -> n_actions), ``critic`` (256 -> 1) and ``centralised_critics.{0,2,4}``
 (obs_dim * num_agents * num_envs -> 512 -> 256 -> 1).  All layers start orthogonal with gain
 sqrt(2) and zero bias (model.py:6-9).  The matrix products run on PyTorch-ROCm (rocBLAS /
-hipBLASLt); nothing here is hand-written HIP."""
+hipBLASLt); nothing here is hand-written HIP; which library call computes a layer is chosen
+per shape for small batches (`_small_gemm_form`)."""
 from __future__ import annotations
 
 import math
+import os
+import warnings
 
 import torch
 from torch import nn
@@ -33,16 +36,107 @@ def _weight_grad(gy, x):
     return torch.bmm(gy.view(S, K // S, -1).transpose(1, 2), x.view(S, K // S, -1)).sum(0)
 
 
+# Below 512 rows (the reference's batch sizes: 16 envs x 2 agents = 32 rows per rollout step)
+# hipBLASLt's pick for the fused call is erratic on MI355X: rows x 512 -> 256 takes 17.8 us at 32
+# rows, 60 us at 128, 118 us at 256 and 6 us at 512, while a plain rocBLAS product takes 3.7 us at
+# all of them (plus two small in-place launches for bias and ReLU); for other layers of the same
+# MLP the fused call wins (rows x 202 -> 512: 5.4 against 7.5 us).  No rule in the shape predicts
+# it, so each (rows, in, out) shape below 512 rows is timed once (both forms replayed from a
+# hipGraph, outside any capture in progress) and the decision kept; MARL_AMD_SMALL_GEMM=fused|plain forces one form.  (profiles/diag/small_gemm2.py)
+_SMALL_ROWS = 512
+_GEMM_CHOICE = {}
+
+
+def gemm_choices():
+    """the decisions taken so far, {(rows, in_features, out_features, relu): "fused" | "plain"}"""
+    return dict(_GEMM_CHOICE)
+
+
+def _fused_linear(x, weight, bias, relu):
+    if relu:
+        return torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+    return torch.addmm(bias, x, weight.t())
+
+
+_blas_switch_announced = False
+
+
+def _announce_blas_switch_quietly():
+    """PyTorch prints a one-time "experimental feature" notice when the preferred BLAS library is
+    set.  Inside an autograd Function the notice is held back until `apply` returns and cannot be
+    filtered where it is raised, so the first switch is made here, outside, with the notice ignored."""
+    global _blas_switch_announced
+    if not _blas_switch_announced:
+        _blas_switch_announced = True
+        blas = torch.backends.cuda.preferred_blas_library
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            blas(blas())
+
+
+def _plain_linear(x, weight, bias, relu):
+    """the product through rocBLAS, bias and ReLU as in-place launches of their own"""
+    blas = torch.backends.cuda.preferred_blas_library
+    prev = blas()
+    blas("hipblas")
+    try:
+        out = torch.mm(x, weight.t())
+    finally:
+        blas(prev)
+    out.add_(bias)
+    return out.relu_() if relu else out
+
+
+def _small_gemm_form(x, weight, bias, relu):
+    rows = x.shape[0]
+    if rows >= _SMALL_ROWS:
+        return "fused"
+    key = (rows, weight.shape[1], weight.shape[0], bool(relu))
+    form = _GEMM_CHOICE.get(key)
+    if form is not None:
+        return form
+    forced = os.environ.get("MARL_AMD_SMALL_GEMM", "auto")
+    if forced in ("fused", "plain"):
+        form = forced
+    elif torch.cuda.is_current_stream_capturing():
+        return "fused"  # cannot time under capture; decided at the next eager call
+    else:
+        # Timed as the small-batch rollouts and updates run them: replayed from a hipGraph.  (Launched
+        # eagerly from Python both forms are bound by the host's launch rate and the form with fewer
+        # launches always looks better, whatever its kernels cost.)
+        times = []
+        for fn in (_fused_linear, _plain_linear):
+            fn(x, weight, bias, relu)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(10):
+                    fn(x, weight, bias, relu)
+            g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                g.replay()
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+            del g
+        # the plain form has to win clearly: a close call must not flip from run to run
+        form = "plain" if times[1] * 1.25 < times[0] else "fused"
+    _GEMM_CHOICE[key] = form
+    return form
+
+
 class _LinearReLU(torch.autograd.Function):
-    """relu(x @ W^T + b) (or without the ReLU) as one GEMM with a fused epilogue; the backward
+    """relu(x @ W^T + b) (or without the ReLU): one GEMM with a fused epilogue, or for the small
+    batches where that call is slow a plain product plus in-place bias and ReLU; the backward
     pass forms the weight gradient with `_weight_grad`."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        if relu:
-            out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        if _small_gemm_form(x, weight, bias, relu) == "plain":
+            out = _plain_linear(x, weight, bias, relu)
         else:
-            out = torch.addmm(bias, x, weight.t())
+            out = _fused_linear(x, weight, bias, relu)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, out if relu else None)
         return out
@@ -59,6 +153,8 @@ class _LinearReLU(torch.autograd.Function):
 
 def _linear(layer: nn.Linear, x, relu):
     if x.is_cuda and x.dim() == 2:
+        if x.shape[0] < _SMALL_ROWS:
+            _announce_blas_switch_quietly()
         return _LinearReLU.apply(x.contiguous(), layer.weight, layer.bias, relu)
     out = layer(x)
     return torch.relu(out) if relu else out

@@ -200,3 +200,37 @@ def test_host_array_mode_fresh_arrays_and_staging_reuse():
     np.testing.assert_array_equal(kept_s[5], copies[5])
     np.testing.assert_array_equal(kept_s[4], copies[4])      # still valid one call later
     assert kept_s[3] is not kept_s[5] and np.shares_memory(kept_s[3], kept_s[5])  # two buffers alternate
+
+
+def test_small_batch_layers_agree_in_both_library_forms(monkeypatch):
+    """Below 512 rows a layer runs either as hipBLASLt's fused call or as a rocBLAS product plus
+    in-place bias and ReLU, whichever was faster when the shape was first seen: both forms give
+    the same numbers up to summation order, forward and backward, and the choice is recorded."""
+    import marl_amd.policy as pol
+    from marl_amd.env import make_env, make_vector_env
+
+    dev = torch.device("cuda:0")
+    vec = make_vector_env(16, make_env(2, "overcooked_cramped_room_v0", "global_obs"), device=dev)
+    torch.manual_seed(3)
+    net = pol.Agent(vec.single_observation_space, vec.single_action_space, 2, 16).to(dev)
+    obs = vec.reset()[0]["n_agent_overcooked_features"]
+    actions = torch.randint(0, 7, (obs.shape[0],), device=dev)
+    results = {}
+    for form in ("fused", "plain"):
+        monkeypatch.setenv("MARL_AMD_SMALL_GEMM", form)
+        pol._GEMM_CHOICE.clear()
+        _, lp, ent, v = net.get_action_and_value(obs, actions)
+        loss = lp.mean() - 0.01 * ent.mean() + 0.5 * (v ** 2).mean()
+        grads = torch.autograd.grad(loss, [p for n, p in net.named_parameters() if not n.startswith("centralised")])
+        assert set(pol.gemm_choices().values()) == {form}
+        results[form] = (lp.detach(), v.detach(), grads)
+    torch.testing.assert_close(results["plain"][0], results["fused"][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(results["plain"][1], results["fused"][1], rtol=1e-5, atol=1e-6)
+    for a, b in zip(results["plain"][2], results["fused"][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    monkeypatch.delenv("MARL_AMD_SMALL_GEMM")
+    pol._GEMM_CHOICE.clear()
+    with torch.no_grad():
+        net.get_action_and_value(obs)
+    assert all(k[0] == obs.shape[0] for k in pol.gemm_choices()) and len(pol.gemm_choices()) >= 3
+    pol._GEMM_CHOICE.clear()
