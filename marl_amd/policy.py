@@ -61,17 +61,26 @@ def _fused_linear(x, weight, bias, relu):
 _blas_switch_announced = False
 
 
-def _announce_blas_switch_quietly():
-    """PyTorch prints a one-time "experimental feature" notice when the preferred BLAS library is
-    set.  Inside an autograd Function the notice is held back until `apply` returns and cannot be
-    filtered where it is raised, so the first switch is made here, outside, with the notice ignored."""
+class _FirstBlasSwitch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        blas = torch.backends.cuda.preferred_blas_library
+        blas(blas())
+        return t
+
+
+def _announce_blas_switch_quietly(t):
+    """PyTorch issues a one-time "experimental feature" notice when the preferred BLAS library is
+    set: as a Python warning when the call happens inside an operator (raised only when the
+    outermost operator returns, here `_LinearReLU.apply`, where it can no longer be filtered at its
+    source), straight to stderr otherwise.  The first switch is therefore made inside a small
+    operator of its own with warnings ignored around it."""
     global _blas_switch_announced
     if not _blas_switch_announced:
         _blas_switch_announced = True
-        blas = torch.backends.cuda.preferred_blas_library
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            blas(blas())
+            _FirstBlasSwitch.apply(t)
 
 
 def _plain_linear(x, weight, bias, relu):
@@ -87,6 +96,15 @@ def _plain_linear(x, weight, bias, relu):
     return out.relu_() if relu else out
 
 
+def _gemv_linear(x, weight, bias, relu):
+    """a single row (the centralised critic's joint observation, model.py:45): matrix-vector product"""
+    out = torch.addmv(bias, weight, x[0]).unsqueeze(0)
+    return out.relu_() if relu else out
+
+
+_FORMS = {"fused": _fused_linear, "plain": _plain_linear, "gemv": _gemv_linear}
+
+
 def _small_gemm_form(x, weight, bias, relu):
     rows = x.shape[0]
     if rows >= _SMALL_ROWS:
@@ -96,8 +114,8 @@ def _small_gemm_form(x, weight, bias, relu):
     if form is not None:
         return form
     forced = os.environ.get("MARL_AMD_SMALL_GEMM", "auto")
-    if forced in ("fused", "plain"):
-        form = forced
+    if forced in ("fused", "plain", "gemv"):
+        form = forced if (forced != "gemv" or rows == 1) else "fused"
     elif torch.cuda.is_current_stream_capturing():
         return "fused"  # cannot time under capture; decided at the next eager call
     else:
@@ -105,7 +123,9 @@ def _small_gemm_form(x, weight, bias, relu):
         # eagerly from Python both forms are bound by the host's launch rate and the form with fewer
         # launches always looks better, whatever its kernels cost.)
         times = []
-        for fn in (_fused_linear, _plain_linear):
+        names = ("fused", "plain", "gemv") if rows == 1 else ("fused", "plain")
+        for name in names:
+            fn = _FORMS[name]
             fn(x, weight, bias, relu)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -120,8 +140,9 @@ def _small_gemm_form(x, weight, bias, relu):
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
             del g
-        # the plain form has to win clearly: a close call must not flip from run to run
-        form = "plain" if times[1] * 1.25 < times[0] else "fused"
+        # another form has to win clearly: a close call must not flip from run to run
+        best = min(range(len(times)), key=lambda k: times[k])
+        form = names[best] if times[best] * 1.25 < times[0] else "fused"
     _GEMM_CHOICE[key] = form
     return form
 
@@ -133,10 +154,7 @@ class _LinearReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        if _small_gemm_form(x, weight, bias, relu) == "plain":
-            out = _plain_linear(x, weight, bias, relu)
-        else:
-            out = _fused_linear(x, weight, bias, relu)
+        out = _FORMS[_small_gemm_form(x, weight, bias, relu)](x, weight, bias, relu)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, out if relu else None)
         return out
@@ -154,7 +172,7 @@ class _LinearReLU(torch.autograd.Function):
 def _linear(layer: nn.Linear, x, relu):
     if x.is_cuda and x.dim() == 2:
         if x.shape[0] < _SMALL_ROWS:
-            _announce_blas_switch_quietly()
+            _announce_blas_switch_quietly(x)
         return _LinearReLU.apply(x.contiguous(), layer.weight, layer.bias, relu)
     out = layer(x)
     return torch.relu(out) if relu else out
@@ -204,7 +222,8 @@ class Agent(nn.Module):
     def _central(self, joint_obs):
         if self.centralised_critics is None:
             raise RuntimeError("this Agent was built without its centralised critic (build_centralised=False)")
-        return self.centralised_critics(joint_obs)
+        c = self.centralised_critics
+        return _linear(c[4], _linear(c[2], _linear(c[0], joint_obs, True), True), False)
 
     def get_value(self, x, joint_obs=None):
         if joint_obs is not None:
