@@ -23,6 +23,7 @@ from .mappo import MAPPO
 
 class CMAPPO(MAPPO):
     centralised = True
+    fused_target = "minibatch_mean"
 
     def compute_value_loss(self, target, new_values):
         centralized_target = target.mean(dim=0, keepdim=True)
@@ -44,3 +45,6 @@ class CMAPPO(MAPPO):
         adv, ret = _gae_kernel(rewards, dones, values, next_values, self.gamma, self.lam, centralised=True,
                                reward_mean=reward_mean, want_returns=want_returns)
         return (adv, ret) if want_returns else adv
+
+
+CMAPPO._value_loss_of_fused_pass = CMAPPO.compute_value_loss

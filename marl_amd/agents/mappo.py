@@ -25,6 +25,7 @@ from ..gae import compute_gae as _gae_kernel
 
 class MAPPO:
     centralised = False
+    fused_target = "own"  # what the one-pass loss regresses a sample's value onto: its own target
 
     def __init__(self, env, optimzer, policy, buffer, single_agent_obs, single_agent_action, batch_size=1,
                  num_mini_batches=4, num_agents=4, ppo_epoch=10, clip_param=0.2, value_loss_coef=0.5,
@@ -52,10 +53,13 @@ class MAPPO:
         self._graph_update = (graph_update == "on" or (graph_update == "auto" and small)) \
             and not dist_utils.collectives_active() and self.device.type == "cuda" and optimzer is not None
         self._g = None
-        # loss + head gradients from one HIP pass (marl_amd.ppo_loss) instead of ~70 autograd ops:
-        # the decentralised loss on the GPU only (CMAPPO's value loss has another form)
-        self._fused_loss = bool(fused_loss) and self.device.type == "cuda" and not self.centralised \
-            and type(self).compute_value_loss is MAPPO.compute_value_loss
+        # loss + head gradients from one HIP pass (marl_amd.ppo_loss) instead of ~70 autograd ops, on
+        # the GPU, for the value losses the pass knows: this class's and CMAPPO's (which regresses
+        # onto the minibatch mean of the targets: the same pass with that mean as every sample's
+        # target).  A subclass with another compute_value_loss falls back to autograd.
+        self._fused_loss = bool(fused_loss) and self.device.type == "cuda" \
+            and type(self).compute_value_loss is getattr(type(self), "_value_loss_of_fused_pass", None)
+        self._mean_target = None
         if self._graph_update:
             for group in optimzer.param_groups:  # the step counter must live on the device to be captured
                 group["capturable"] = True
@@ -74,10 +78,11 @@ class MAPPO:
         log-probabilities and values are written into their rows by the kernels that produce them,
         the int64 actions into `actions_out` (the env reads them there; the driver converts a
         whole rollout of them to the store's float32 at once, `store_actions`).  Call `step` of a
-        rollout draws with call number rollout * num_steps + step.  Decentralised critic with
-        fused sampling only."""
+        rollout draws with call number rollout * num_steps + step.  Needs fused sampling; with the
+        centralised critic every row receives the one joint value."""
         buf = self.buffer
-        return self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step], actions_out, slot=step)
+        return self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step], actions_out, slot=step,
+                                        joint=self.centralised)
 
     def begin_direct_rollouts(self, num_steps):
         self.policy.sampler.use_slots(num_steps)
@@ -92,7 +97,7 @@ class MAPPO:
         self.policy.sampler.advance_round()
 
     def can_act_into(self):
-        return not self.centralised and getattr(self.policy, "sampler", None) is not None
+        return getattr(self.policy, "sampler", None) is not None
 
     def add_to_buffer(self, obs, actions, rewards, dones, logprobs, values):
         self.buffer.add(obs, actions, rewards, dones, logprobs, values)
@@ -118,6 +123,12 @@ class MAPPO:
             from ..ppo_loss import ppo_loss
 
             logits, newvalue = self.policy.logits_and_value(b_obs[mb])
+            if self.fused_target == "minibatch_mean":
+                # agents/CentralizedMAPPO.py:36-46: every sample regresses onto the mean target of its minibatch
+                if self._mean_target is None or self._mean_target.shape != b_value_target.shape:
+                    self._mean_target = torch.empty_like(b_value_target)
+                self._mean_target.copy_(b_value_target[mb].mean().expand_as(self._mean_target))
+                b_value_target = self._mean_target
             loss, stats = ppo_loss(logits, newvalue, mb, b_actions_f, b_logprobs, b_advantages, b_value_target,
                                    self.clip_param, self.entropy_coef, self.value_loss_coef)
             self.optimizer.zero_grad()
@@ -254,3 +265,6 @@ class MAPPO:
     def get_grad_norm(self, module):
         sq = [p.grad.detach().norm(2) ** 2 for p in module.parameters() if p.grad is not None]
         return float(torch.stack(sq).sum().sqrt()) if sq else 0.0
+
+
+MAPPO._value_loss_of_fused_pass = MAPPO.compute_value_loss

@@ -261,15 +261,25 @@ class Agent(nn.Module):
             torch.cat([self.actor.weight, self.critic.weight], out=self._head_w)
             torch.cat([self.actor.bias, self.critic.bias], out=self._head_b)
 
-    def rollout_step(self, x, logprob_out, value_out, actions_out=None, slot=None):
+    def rollout_step(self, x, logprob_out, value_out, actions_out=None, slot=None, joint=False):
         """The rollout half of `get_action_and_value` for the decentralised critic, writing the
         log-probabilities and the values straight into the given rows of the rollout store
         (float32 [rows] each) instead of returning fresh tensors that are then copied.  Both
         heads come out of one GEMM (`refresh_rollout_heads`), the sampling kernel hands the value
         column on: three launches after the trunk instead of five.  The numbers agree with
-        `get_action_and_value` to float32 rounding; needs `use_fused_sampling`, no autograd."""
+        `get_action_and_value` to float32 rounding; needs `use_fused_sampling`, no autograd.
+        `joint=True`: the value is the centralised critic's, one number for the concatenation of all
+        rows (agents/MAPPO.py:70-73, model.py:45), written to every row as the reference's buffer
+        assignment broadcasts it (agent_environment.py:83-84, buffer.py:28)."""
         if self.sampler is None:
             raise RuntimeError("rollout_step needs use_fused_sampling()")
+        if joint:
+            with torch.no_grad():
+                logits = _linear(self.actor, self._trunk(x), False)
+                actions, _, _ = self.sampler.sample(logits, want_entropy=False, actions_out=actions_out,
+                                                    logprob_out=logprob_out, slot=slot)
+                value_out.copy_(self._central(x.view(1, -1)).view(1).expand_as(value_out))
+            return actions
         if getattr(self, "_head_w", None) is None:
             self.refresh_rollout_heads()
         with torch.no_grad():

@@ -1,4 +1,5 @@
-"""The clipped-surrogate loss of a PPO minibatch (agents/MAPPO.py:167-200, decentralised critic)
+"""The clipped-surrogate loss of a PPO minibatch (agents/MAPPO.py:167-200; the caller supplies each
+sample's value target, its own for MAPPO, the minibatch mean for CMAPPO)
 with its gradients for the two network heads, from libmarl_amd.so `marl_ppo_loss`: two launches
 in place of the ~70 small tensor ops autograd runs for the same arithmetic (Categorical
 log-probability and entropy, ratio, clipping, the three means, and all their backward ops).

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler, layout="overcooked_cramped_room_v0",
-           feature="global_obs", seed=9):
-    from marl_amd.agents import MAPPO
+           feature="global_obs", seed=9, centralised=False):
+    from marl_amd.agents import CMAPPO, MAPPO
     from marl_amd.env import make_env, make_vector_env
     from marl_amd.layouts import get_layout
     from marl_amd.policy import Agent
@@ -27,7 +27,7 @@ def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler
     env = make_env(A, layout, feature, max_steps=max_steps)
     snaps = []
 
-    class Recorder(MAPPO):
+    class Recorder(CMAPPO if centralised else MAPPO):
         def update(self, next_obs):  # keep what was collected, learn nothing
             snap = {k: getattr(self.buffer, k + "_buff").clone() for k in
                     ("obs", "actions", "rewards", "dones", "logprobs", "values")}
@@ -44,7 +44,7 @@ def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler
     buf = Buffer(vec.D, A, E, max_size=T, device=dev)
     args = types.SimpleNamespace(num_steps=T, num_envs=E, num_agents=A, log=False, graph_rollout=graph_rollout)
     agent = Recorder(vec, None, net, buf, None, None, batch_size=E * A * T, num_agents=A, args=args)
-    assert agent.can_act_into() == fused_sampler
+    assert agent.can_act_into() == fused_sampler and agent.centralised == centralised
     torch.manual_seed(1)
     returns, freq = agent_environment_loop(agent, vec, dev, num_update=updates, args=args)
     assert len(snaps) == updates
@@ -95,4 +95,23 @@ def test_four_agents_local_obs_and_uneven_lengths(oracle_mod):
     for u, (got, want) in enumerate(zip(snaps, ref)):
         for k in ("obs", "actions", "rewards", "dones", "next_obs"):
             np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+    assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)
+
+
+@pytest.mark.parametrize("fused_sampler", [False, True])
+def test_centralised_learner_stores_the_joint_value_in_every_row(oracle_mod, fused_sampler):
+    """CMAPPO through the same driver (step-by-step store without the fused sampler, straight into
+    the store with it): rows as the reference loop stores them, and as value of every row of a step
+    the centralised critic's one number for the concatenated observations (agents/MAPPO.py:70-73,
+    agent_environment.py:83-84)."""
+    E, A, T, updates, max_steps = 4, 2, 8, 4, 6
+    snaps, ref, returns, _, ref_returns, _, net, _ = _drive(oracle_mod, E, A, T, updates, max_steps, "on", fused_sampler,
+                                                           layout="overcooked_forced_coordination_v0", centralised=True)
+    for u, (got, want) in enumerate(zip(snaps, ref)):
+        for k in ("obs", "actions", "rewards", "dones", "next_obs"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+        for t in range(T):
+            with torch.no_grad():
+                v = net.get_value(got["obs"][t], joint_obs=got["obs"][t].reshape(1, -1))
+            torch.testing.assert_close(got["values"][t], v.view(1).expand(E * A), rtol=1e-5, atol=1e-6)
     assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "update_golden.npz")
 STRIDE = 41
 
 
-@pytest.mark.parametrize("name,fused_loss", [("mappo", True), ("mappo", False), ("cmappo", True)])
+@pytest.mark.parametrize("name,fused_loss", [("mappo", True), ("mappo", False), ("cmappo", True), ("cmappo", False)])
 def test_update_reproduces_the_references_parameters(name, fused_loss):
     from marl_amd.agents import CMAPPO, MAPPO
     from marl_amd.policy import Agent
@@ -49,7 +49,7 @@ def test_update_reproduces_the_references_parameters(name, fused_loss):
     agent = cls(env, opt, net, buf, (D,), K, batch_size=T * N, num_mini_batches=4, num_agents=A, ppo_epoch=3,
                 clip_param=0.2, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5, gamma=0.99, lam=0.95,
                 args=args, shuffle="numpy", graph_update="off", fused_loss=fused_loss)
-    assert agent._fused_loss == (fused_loss and name == "mappo")  # loss from the HIP pass / from autograd
+    assert agent._fused_loss == fused_loss  # loss from the HIP pass / from autograd
     np.random.seed(777)
     agent.update(next_obs)
 
