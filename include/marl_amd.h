@@ -178,6 +178,16 @@ int marl_reward_events(const float *d_rewards, int num_envs, int num_agents, uin
 size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
 
 /*
+ * The same bookkeeping for num_steps steps at once: d_rewards float32 [num_steps][num_envs * num_agents]
+ * (e.g. the rows a rollout has just stored, agent_environment.py:63-76 applied to each in turn).
+ * Results equal num_steps marl_reward_events calls in step order, bit for bit (the rows-0..1 return is
+ * accumulated step after step).  d_workspace: marl_reward_events_many_workspace_bytes() bytes, 8-byte aligned.
+ */
+int marl_reward_events_many(const float *d_rewards, int num_steps, int num_envs, int num_agents,
+                            uint64_t *d_totals, double *d_first_rows, void *d_workspace, void *stream);
+size_t marl_reward_events_many_workspace_bytes(int num_steps, int num_envs, int num_agents);
+
+/*
  * marl_reward_events for callers that cannot allocate device memory or carry a workspace along:
  * code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc.  No
  * counterpart in the reference.  Same arguments and bit-identical results, minus d_workspace:

@@ -16,7 +16,7 @@ EXPORTS = (
     "marl_env_num_pots", "marl_env_grid_cells", "marl_env_state_words", "marl_env_state_bytes",
     "marl_env_reset", "marl_env_step", "marl_env_step_many", "marl_env_featurize", "marl_env_export_state",
     "marl_env_import_state", "marl_gae", "marl_gae_workspace_bytes", "marl_row_sums",
-    "marl_reward_events", "marl_reward_events_workspace_bytes", "marl_reward_events_noalloc", "marl_sample_categorical",
+    "marl_reward_events", "marl_reward_events_workspace_bytes", "marl_reward_events_noalloc", "marl_reward_events_many", "marl_reward_events_many_workspace_bytes", "marl_sample_categorical",
     "marl_ppo_loss", "marl_ppo_loss_workspace_bytes",
 )
 
@@ -75,6 +75,10 @@ def lib() -> ctypes.CDLL:
     L.marl_reward_events.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     L.marl_reward_events_workspace_bytes.restype = ctypes.c_size_t
     L.marl_reward_events_workspace_bytes.argtypes = [ci, ci]
+    L.marl_reward_events_many.restype = ci
+    L.marl_reward_events_many.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+    L.marl_reward_events_many_workspace_bytes.restype = ctypes.c_size_t
+    L.marl_reward_events_many_workspace_bytes.argtypes = [ci, ci, ci]
     L.marl_reward_events_noalloc.restype = ci
     L.marl_reward_events_noalloc.argtypes = [vp, ci, ci, vp, vp, vp]
     L.marl_sample_categorical.restype = ci

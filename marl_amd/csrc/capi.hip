@@ -50,6 +50,8 @@ hipError_t launch_ppo_loss(const float* logits, int M, int K, int ld, const floa
                            float* grad_logits, float* grad_values, double* stats, double* partial, hipStream_t stream);
 hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* partial, uint64_t* totals,
                                 double* first_rows, hipStream_t stream);
+hipError_t launch_reward_events_many(const float* rewards, int K, int E, int A, uint64_t* partial, uint64_t* totals,
+                                     double* first_rows, hipStream_t stream);
 }  // namespace oc
 
 using namespace oc;
@@ -735,6 +737,25 @@ extern "C" int marl_reward_events(const float* d_rewards, int num_envs, int num_
         return fail(MARL_ERR_INVALID, "d_totals, d_first_rows and d_workspace must be 8-byte aligned");
     hipError_t e = launch_reward_events(d_rewards, num_envs, num_agents, reinterpret_cast<uint64_t*>(d_workspace), d_totals,
                                         d_first_rows, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MARL_OK : fail_hip(e, "reward event kernel launch");
+}
+
+extern "C" size_t marl_reward_events_many_workspace_bytes(int num_steps, int num_envs, int num_agents) {
+    if (num_steps <= 0 || num_envs <= 0 || num_agents <= 0) return 0;
+    return (size_t)num_steps * (size_t)reward_event_chunks(num_envs * num_agents) * 4 * sizeof(uint64_t);
+}
+
+extern "C" int marl_reward_events_many(const float* d_rewards, int num_steps, int num_envs, int num_agents,
+                                       uint64_t* d_totals, double* d_first_rows, void* d_workspace, void* stream) {
+    if (!d_rewards || !d_totals || !d_workspace) return fail(MARL_ERR_INVALID, "NULL argument to marl_reward_events_many");
+    if (num_steps <= 0 || num_steps > 65535) return fail(MARL_ERR_INVALID, "num_steps must be in [1, 65535]");
+    if (num_envs <= 0 || num_agents <= 0 || (int64_t)num_envs * num_agents > 0x7FFFFFFF)
+        return fail(MARL_ERR_INVALID, "num_envs and num_agents must be positive and their product below 2^31");
+    if (((uintptr_t)d_workspace & 7u) != 0 || ((uintptr_t)d_totals & 7u) != 0 || ((uintptr_t)d_first_rows & 7u) != 0)
+        return fail(MARL_ERR_INVALID, "d_totals, d_first_rows and d_workspace must be 8-byte aligned");
+    hipError_t e = launch_reward_events_many(d_rewards, num_steps, num_envs, num_agents,
+                                             reinterpret_cast<uint64_t*>(d_workspace), d_totals, d_first_rows,
+                                             reinterpret_cast<hipStream_t>(stream));
     return e == hipSuccess ? MARL_OK : fail_hip(e, "reward event kernel launch");
 }
 

@@ -114,6 +114,70 @@ hipError_t launch_reward_events(const float* rewards, int E, int A, uint64_t* pa
 }
 
 // ---------------------------------------------------------------------------------------
+// Several steps at once (rewards [K][E * A], e.g. the rows a rollout has just stored): block (c, k)
+// scans chunk c of step k, then one block adds everything to the totals and walks the steps in
+// order for the rows-0..1 part, so the result equals K single-step calls bit for bit (the
+// rows-0..1 return is a double accumulated step after step, like the reference's Python float).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EVENT_BLOCK)
+reward_events_many_partial_kernel(const float* __restrict__ rewards, int E, int A, uint64_t* __restrict__ partial) {
+    const float* step_rewards = rewards + (size_t)blockIdx.y * (size_t)E * A;
+    uint32_t tenths = 0, deliv = 0, plate = 0, pot = 0;
+    for (int e = blockIdx.x * EVENT_BLOCK + threadIdx.x; e < E; e += gridDim.x * EVENT_BLOCK) {
+        bool d = false, p = false, o = false;
+        for (int a = 0; a < A; ++a) {
+            const float r = step_rewards[(size_t)e * A + a];
+            tenths += (uint32_t)(r * 10.0f + 0.5f);
+            d |= r >= 1.0f;
+            p |= r == 0.3f;
+            o |= r == 0.1f;
+        }
+        deliv += d; plate += p; pot += o;
+    }
+    uint64_t v[4] = {tenths, deliv, plate, pot};
+    __shared__ uint64_t part[EVENT_BLOCK / 64][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t s = 0;
+        for (int w = 0; w < EVENT_BLOCK / 64; ++w) s += part[w][threadIdx.x];
+        partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+reward_events_many_finish_kernel(const float* __restrict__ rewards, int N, int K, const uint64_t* __restrict__ partial,
+                                 int C, uint64_t* __restrict__ totals, double* __restrict__ first_rows) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t s = 0;
+    for (int c = lane; c < C * K; c += 64) s += partial[(size_t)c * 4 + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) totals[k] += s;
+    if (threadIdx.x == 255 && first_rows)
+        for (int step = 0; step < K; ++step) first_rows_update(rewards + (size_t)step * N, N, first_rows);
+}
+
+hipError_t launch_reward_events_many(const float* rewards, int K, int E, int A, uint64_t* partial, uint64_t* totals,
+                                     double* first_rows, hipStream_t stream) {
+    const int C = reward_event_chunks(E * A);
+    hipLaunchKernelGGL(reward_events_many_partial_kernel, dim3(C, K), dim3(EVENT_BLOCK), 0, stream, rewards, E, A, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reward_events_many_finish_kernel, dim3(1), dim3(256), 0, stream, rewards, E * A, K, partial, C, totals,
+                       first_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // The same pass for callers that may not allocate (code under hipGraph capture, serving loops,
 // harnesses with a no-allocation rule): the per-chunk partial sums, the one piece of scratch this
 // pass needs, live in a file-scope device array instead of a caller-supplied workspace.  Every

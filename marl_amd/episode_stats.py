@@ -25,6 +25,7 @@ class EpisodeStats:
         nbytes = int(_lib.lib().marl_reward_events_workspace_bytes(self.E, self.A))
         self._workspace = torch.empty(max(nbytes, 8) // 8, dtype=torch.int64, device=self.device)
         self.steps = 0
+        self._many_workspace = None
 
     def add(self, rewards: torch.Tensor) -> None:
         """Adds one step's rewards (float32 [E*A] on the GPU, env-major)."""
@@ -39,6 +40,28 @@ class EpisodeStats:
                 ctypes.c_void_p(self.first_rows.data_ptr()), ctypes.c_void_p(self._workspace.data_ptr()), stream),
                 "marl_reward_events")
         self.steps += 1
+
+    def add_many(self, rewards: torch.Tensor) -> None:
+        """Adds several steps' rewards at once (float32 [K, E*A], contiguous): the same totals as K
+        `add` calls in order, from two launches instead of up to 2 K."""
+        if rewards.dtype != torch.float32 or not rewards.is_cuda or not rewards.is_contiguous() or rewards.dim() != 2:
+            raise ValueError("rewards must be a contiguous float32 [steps, rows] tensor on the GPU")
+        K = int(rewards.shape[0])
+        if rewards.shape[1] != self.E * self.A:
+            raise ValueError(f"rewards has {rewards.shape[1]} entries per step, expected {self.E * self.A}")
+        if K == 0:
+            return
+        L = _lib.lib()
+        need = max(int(L.marl_reward_events_many_workspace_bytes(K, self.E, self.A)), 8) // 8
+        if self._many_workspace is None or self._many_workspace.numel() < need:
+            self._many_workspace = torch.empty(need, dtype=torch.int64, device=self.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(L.marl_reward_events_many(
+                ctypes.c_void_p(rewards.data_ptr()), K, self.E, self.A, ctypes.c_void_p(self.totals.data_ptr()),
+                ctypes.c_void_p(self.first_rows.data_ptr()), ctypes.c_void_p(self._many_workspace.data_ptr()), stream),
+                "marl_reward_events_many")
+        self.steps += K
 
     def raw(self):
         """(totals int64[4], first_rows float64[4]) as device tensors, without a host sync."""

@@ -124,7 +124,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         if direct:
             agent.act_into(obs, step, act_rows[step])
             env.step_into(act_rows[step], slot(step + 1), buf.rewards_buff[step], term_rows[step], trunc_rows[step])
-            stats.add(buf.rewards_buff[step])
+            # (the reward events of these steps are counted per segment, from the stored rows: run_segment)
             buf.ptr = (step + 1) % buf.max_size
             buf.size = min(max(buf.size, step + 1), buf.max_size)
             return
@@ -157,12 +157,16 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         if not (use_graphs and warm):
             for step in range(first, first + count):
                 one_step(step)
+            if direct:
+                stats.add_many(buf.rewards_buff[first:first + count])
             return
         if count == collect_steps:
             replay_run(first, count)  # a whole rollout: one graph
         else:
             for f, c in aligned_runs(first, count):
                 replay_run(f, c)
+        if direct:
+            stats.add_many(buf.rewards_buff[first:first + count])
         buf.ptr = (first + count) % buf.max_size
         buf.size = min(first + count, buf.max_size)
 

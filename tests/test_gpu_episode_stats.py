@@ -46,3 +46,29 @@ def test_rejects_bad_rewards():
         stats.add(torch.zeros(7, dtype=torch.float32, device="cuda"))
     with pytest.raises(ValueError):
         stats.add(torch.zeros(8, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("E,A,K", [(1, 2, 1), (16, 2, 7), (257, 4, 5), (5000, 2, 33)])
+def test_many_steps_at_once_equal_single_steps(oracle_mod, E, A, K):
+    """marl_reward_events_many over K stored steps == K marl_reward_events calls in order, exactly
+    (integer totals; the rows-0..1 return is a double accumulated step after step)."""
+    from marl_amd.episode_stats import EpisodeStats
+
+    rng = np.random.default_rng(E + K)
+    p = np.full(_POSSIBLE.size, 0.03)
+    p[0] = 1.0 - 0.03 * (_POSSIBLE.size - 1)
+    r = rng.choice(_POSSIBLE, size=(K, E * A), p=p).astype(np.float32)
+    rd = torch.from_numpy(r).cuda()
+    one, many = EpisodeStats(E, A, "cuda"), EpisodeStats(E, A, "cuda")
+    for k in range(K):
+        one.add(rd[k])
+    many.add_many(rd)
+    many.add_many(rd[:0])
+    assert torch.equal(one.raw()[0], many.raw()[0]) and torch.equal(one.raw()[1], many.raw()[1])
+    assert one.steps == many.steps == K
+    totals = np.zeros(4, np.int64); first = np.zeros(4, np.float64)
+    for k in range(K):
+        t, f = oracle_mod.reward_events(r[k], E, A)
+        totals += t; first += f
+    np.testing.assert_array_equal(many.raw()[0].cpu().numpy(), totals)
+    np.testing.assert_array_equal(many.raw()[1].cpu().numpy(), first)
