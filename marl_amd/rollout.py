@@ -21,7 +21,8 @@ Episode statistics keep the reference's definition (agent_environment.py:66-76,8
 0..1 only, whatever the agent count; a delivery is any reward >= 1, a plating == 0.3, an
 onion-in-pot == 0.1; the return is the sum over steps of the mean reward of those rows) and add
 the same quantities averaged over every env of every rank; both come from one small kernel
-pass per step (`episode_stats.EpisodeStats`).
+pass (`episode_stats.EpisodeStats`): per step, or, when the rewards go straight into the rollout
+store, once per run of steps over the stored rows.
 """
 from __future__ import annotations
 

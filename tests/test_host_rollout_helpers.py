@@ -1,0 +1,34 @@
+"""Host-side helpers of the rollout driver and the bench that need no GPU."""
+import os
+
+
+def test_aligned_runs_cover_the_segment_with_aligned_powers_of_two():
+    from marl_amd.rollout import aligned_runs
+
+    seen = set()
+    for T in (12, 128, 200):
+        for first in range(T):
+            for count in range(1, T - first + 1):
+                runs = aligned_runs(first, count)
+                pos = first
+                for start, length in runs:
+                    assert start == pos and length & (length - 1) == 0 and start % length == 0
+                    pos += length
+                assert pos == first + count
+                assert len(runs) <= 2 * max(count.bit_length(), 1)
+                if T == 128:
+                    seen.update(runs)
+    assert len(seen) < 2 * 128  # a bounded set of graphs whatever the episode length
+    assert aligned_runs(0, 128) == [(0, 128)] and aligned_runs(5, 0) == []
+
+
+def test_bench_counts_the_cores_this_process_may_use(monkeypatch):
+    import bench
+
+    monkeypatch.setenv("OMP_NUM_THREADS", "3")
+    threads, total, affinity, share = bench.host_threads()
+    assert share == 3 and threads == min(3, total, affinity) and total == (os.cpu_count() or 1)
+    monkeypatch.delenv("OMP_NUM_THREADS")
+    threads, total, affinity, share = bench.host_threads()
+    assert share == 0 and threads == min(total, affinity)
+    assert bench.algorithmic_bytes_per_agent_step(202, 5, 2, 8) == 842.0
