@@ -69,12 +69,13 @@ def test_stored_rollouts_match_the_reference_loop(oracle_mod, graph_rollout, fus
     for u, (got, want) in enumerate(zip(snaps, ref)):
         for k in ("obs", "actions", "rewards", "dones", "next_obs"):
             np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
-        # log-probabilities and values are those of the policy on the stored observations
+        # log-probabilities and values are those of the policy on the stored observations (to float32
+        # summation order: a 16-row rollout step and this 256-row call may run different GEMM kernels)
         with torch.no_grad():
             _, lp, _, v = net.get_action_and_value(got["obs"].reshape(-1, got["obs"].shape[-1]),
                                                    got["actions"].reshape(-1).long())
-        torch.testing.assert_close(got["logprobs"].reshape(-1), lp, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(got["values"].reshape(-1), v.squeeze(1), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got["logprobs"].reshape(-1), lp, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(got["values"].reshape(-1), v.squeeze(1), rtol=1e-4, atol=1e-5)
     # 80 steps = 7 episodes of 11 driver steps; the row after each truncation carries dones = 1
     dones = np.concatenate([s["dones"][:, 0].cpu().numpy() for s in snaps])
     assert list(np.nonzero(dones)[0]) == [k for k in range(T * updates) if k % (max_steps + 1) == max_steps]
@@ -113,5 +114,5 @@ def test_centralised_learner_stores_the_joint_value_in_every_row(oracle_mod, fus
         for t in range(T):
             with torch.no_grad():
                 v = net.get_value(got["obs"][t], joint_obs=got["obs"][t].reshape(1, -1))
-            torch.testing.assert_close(got["values"][t], v.view(1).expand(E * A), rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(got["values"][t], v.view(1).expand(E * A), rtol=1e-4, atol=1e-5)
     assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)

@@ -224,8 +224,8 @@ def test_small_batch_layers_agree_in_both_library_forms(monkeypatch):
         grads = torch.autograd.grad(loss, [p for n, p in net.named_parameters() if not n.startswith("centralised")])
         assert set(pol.gemm_choices().values()) == {form}
         results[form] = (lp.detach(), v.detach(), grads)
-    torch.testing.assert_close(results["plain"][0], results["fused"][0], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(results["plain"][1], results["fused"][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(results["plain"][0], results["fused"][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(results["plain"][1], results["fused"][1], rtol=1e-4, atol=1e-5)
     for a, b in zip(results["plain"][2], results["fused"][2]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
     monkeypatch.delenv("MARL_AMD_SMALL_GEMM")
