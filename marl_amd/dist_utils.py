@@ -5,6 +5,7 @@ reference's ``loss.backward()`` and ``clip_grad_norm_``, agents/MAPPO.py:207-208
 episode-statistic reductions, and for centralised MAPPO the per-step reward mean."""
 from __future__ import annotations
 
+import atexit
 import os
 
 import torch
@@ -32,7 +33,13 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, **kwargs)
+        atexit.register(_shutdown)
     return rank, local_rank, world
+
+
+def _shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def world_size():
