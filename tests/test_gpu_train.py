@@ -234,3 +234,19 @@ def test_small_batch_layers_agree_in_both_library_forms(monkeypatch):
         net.get_action_and_value(obs)
     assert all(k[0] == obs.shape[0] for k in pol.gemm_choices()) and len(pol.gemm_choices()) >= 3
     pol._GEMM_CHOICE.clear()
+
+
+def test_mappo_learns_cramped_room_within_six_million_steps(tmp_path):
+    """Regression guard for the whole loop (rollout, restart, GAE, PPO update): at 256 envs the
+    all-env episode return, 0.2 under random play, passes 2 within twelve episodes (it reached 7
+    in the recorded run, results/r01_cramped_mappo)."""
+    E, A, T = 256, 2, 128
+    episodes = 12
+    updates = (episodes * 1001) // T + 1
+    _, freq = _run(["--num-agents", str(A), "--num-envs", str(E), "--layout", "overcooked_cramped_room_v0",
+                    "--num-steps", str(T), "--num-minibatches", "4", "--total-steps", str(E * A * T * updates),
+                    "--ppo-epoch", "4", "--clip-param", "0.2", "--value-loss-coef", "0.5", "--entropy-coef", "0.01",
+                    "--lr", "3e-4", "--feature", "global_obs", "--seed", "1", "--data-path", str(tmp_path)])
+    curve = freq["episode_return_all_envs"]
+    assert len(curve) == episodes
+    assert curve[0] < 0.6 and curve[-1] > 2.0 and curve[-1] > 4 * curve[0], curve
