@@ -112,9 +112,10 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
         env.step_into(actions[i % R], store[i % 2], rew, term, trunc)
     us = timed(lambda i: env.step_into(actions[i % R], store[i % 2], rew, term, trunc), 1024, dev)
     out["llc_resident"] = {
-        "regime": "obs_ring=2: 212 MB of rows stay in the 256 MiB last-level cache and are overwritten there; "
-                  "cache-resident store rate, NOT HBM bandwidth",
-        "bound": "llc", "us_per_launch": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
+        "regime": (f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows stay in the 256 MiB last-level cache and are overwritten "
+                   "there; cache-resident store rate, NOT HBM bandwidth") if 2 * N * D * 4 <= (256 << 20) else
+                  f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows, more than the 256 MiB last-level cache holds: they drain to HBM",
+        "bound": "llc" if 2 * N * D * 4 <= (256 << 20) else "hbm", "us_per_launch": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
         "frac_of_hbm_spec": frac(us)}
 
     # the multi-step launch, rows kept
@@ -179,6 +180,10 @@ def main():
     ap.add_argument("--layout", default="overcooked_cramped_room_v0")
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--feature", default="global_obs")
+    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=None,
+                    help="preset of a BASELINE.json config: 2 (default workload) cramped_room / 2 agents / 65,536 envs / global_obs; "
+                         "4 counter_circuit / 2 agents / 131,072 envs per GPU (1 M envs over 8 GPUs) / global_obs; "
+                         "5 coordination_ring / 4 agents / 65,536 envs / local_obs")
     ap.add_argument("--graph", action="store_true", help="replay the steps from a hipGraph of 32 launches instead of launching eagerly")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch every step eagerly from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,6 +197,10 @@ def main():
                     help="random: pre-generated uniform actions (headline); policy: the timed steps sample their actions "
                          "from the reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm)")
     args = ap.parse_args()
+    if args.config == 4:
+        args.layout, args.agents, args.feature, args.envs = "overcooked_counter_circuit_v0", 2, "global_obs", 131072
+    elif args.config == 5:
+        args.layout, args.agents, args.feature, args.envs = "overcooked_coordination_ring_v0", 4, "local_obs", 65536
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
