@@ -77,7 +77,11 @@ def replay(rec, device=None):
     dev = env.device
     spawn = torch.from_numpy((cells[..., 0] * W + cells[..., 1]).astype(np.uint8).reshape(N)).to(dev)
     dirs = torch.from_numpy(np.asarray(rec["spawn_dirs"]).astype(np.uint8).reshape(N)).to(dev)
-    obs = torch.empty((K + 1, N, D), dtype=torch.float32, device=dev)
+    # every step's rows start 16-byte aligned (the kernel's requirement): when N * D is no multiple of
+    # four floats, each step's slab is padded to one
+    slab = (N * D + 3) // 4 * 4
+    obs_store = torch.empty((K + 1, slab), dtype=torch.float32, device=dev)
+    obs = [obs_store[k, :N * D].view(N, D) for k in range(K + 1)]
     env.reset(out=obs[0], spawn_override=spawn, dir_override=dirs)
     want_state = any(k in rec for k in ("agents", "pots", "items"))
     states = [env.export_state()] if want_state else []
@@ -94,8 +98,8 @@ def replay(rec, device=None):
             if want_state:
                 states.append(env.export_state())
     else:
-        env.step_many_into(act, obs[1:], rew, term, trunc, prio_override=prio)
-    produced = {"obs": obs.cpu().numpy().reshape(K + 1, E, A, D), "rewards": rew.cpu().numpy().reshape(K, E, A),
+        env.step_many_into(act, obs_store[1:].view(K, N, D), rew, term, trunc, prio_override=prio)
+    produced = {"obs": obs_store[:, :N * D].cpu().numpy().reshape(K + 1, E, A, D), "rewards": rew.cpu().numpy().reshape(K, E, A),
                 "truncated": trunc.cpu().numpy().reshape(K, E, A)}
     if want_state:
         produced["agents"] = np.stack([s["agents"] for s in states])

@@ -1,7 +1,7 @@
-"""Writes tests/golden/replay_cramped_room.npz: one 240-step episode over 8 cramped_room envs in
-the replay harness's recording format, produced by THIS repository's CPU oracle (explicit spawn
+"""Writes the replay recordings under tests/golden/ (replay_*.npz): one episode each over a few envs
+in the replay harness's recording format, produced by THIS repository's CPU oracle (explicit spawn
 cells, directions and serving ranks; biased towards interactions so that soups get cooked).
-It is a regression fixture for oracle and kernel, not a vector from the reference: the
+They are regression fixtures for oracle and kernel, not vectors from the reference: the
 reference's env (cogrid) is not available here.  Run from the repository root."""
 import os
 import sys
@@ -12,30 +12,37 @@ sys.path.insert(0, os.getcwd())
 import oracle  # noqa: E402
 from marl_amd.layouts import get_layout  # noqa: E402
 
-rows = get_layout("overcooked_cramped_room_v0")
-H, W = len(rows), len(rows[0])
-E, A, K = 8, 2, 240
-rng = np.random.default_rng(2024)
-floor = np.array([(r, c) for r in range(H) for c in range(W) if rows[r][c] in " +"])
-cells = np.stack([floor[rng.permutation(len(floor))[:A]] for _ in range(E)])
-dirs = rng.integers(0, 4, size=(E, A))
-ora = oracle.OracleVecEnv(rows, A, "global_obs", max_steps=K, num_envs=E, seed=0, auto_reset=False)
-obs = [ora.reset(spawn_override=(cells[..., 0] * W + cells[..., 1]).astype(np.uint8).reshape(-1),
-                 dir_override=dirs.astype(np.uint8).reshape(-1))]
-snaps = [(ora.agents.copy(), ora.pots.copy(), ora.items.copy())]
-acts = rng.choice(7, size=(K, E, A), p=[0.15, 0.15, 0.15, 0.15, 0.3, 0.03, 0.07])
-rank = rng.integers(0, 200, size=(K, E, A))
-rew, trunc = [], []
-for k in range(K):
-    o, r, _, tr = ora.step(acts[k].reshape(-1).astype(np.int64), prio_override=rank[k].reshape(-1).astype(np.uint8))
-    obs.append(o); rew.append(r); trunc.append(tr)
-    snaps.append((ora.agents.copy(), ora.pots.copy(), ora.items.copy()))
-D = obs[0].shape[1]
-np.savez_compressed(
-    os.path.join("tests", "golden", "replay_cramped_room.npz"),
-    layout=np.array(rows), feature=np.array("global_obs"), max_steps=np.array(K), spawn_cells=cells.astype(np.int16),
-    spawn_dirs=dirs.astype(np.int8), actions=acts.astype(np.int8), serve_rank=rank.astype(np.uint8),
-    obs=np.stack(obs).reshape(K + 1, E, A, D).astype(np.int8), rewards=np.stack(rew).reshape(K, E, A),
-    truncated=np.stack(trunc).reshape(K, E, A), agents=np.stack([s[0] for s in snaps]).astype(np.int16),
-    pots=np.stack([s[1] for s in snaps]).astype(np.int16), items=np.stack([s[2] for s in snaps]).astype(np.uint8))
-print("rewards earned:", float(np.stack(rew).sum()), "truncated at the end:", bool(np.stack(trunc)[-1].all()))
+# name, layout, agents, feature, envs, steps, seed
+SPECS = [
+    ("replay_cramped_room", "overcooked_cramped_room_v0", 2, "global_obs", 8, 240, 2024),
+    ("replay_ring_4_agents", "overcooked_coordination_ring_v0", 4, "local_obs", 6, 200, 7),
+    ("replay_cramped_3_agents", "overcooked_cramped_room_v0", 3, "global_obs", 5, 200, 11),
+]
+
+for name, layout, A, feature, E, K, seed in SPECS:
+    rows = get_layout(layout)
+    H, W = len(rows), len(rows[0])
+    rng = np.random.default_rng(seed)
+    floor = np.array([(r, c) for r in range(H) for c in range(W) if rows[r][c] in " +"])
+    cells = np.stack([floor[rng.permutation(len(floor))[:A]] for _ in range(E)])
+    dirs = rng.integers(0, 4, size=(E, A))
+    ora = oracle.OracleVecEnv(rows, A, feature, max_steps=K, num_envs=E, seed=0, auto_reset=False)
+    obs = [ora.reset(spawn_override=(cells[..., 0] * W + cells[..., 1]).astype(np.uint8).reshape(-1),
+                     dir_override=dirs.astype(np.uint8).reshape(-1))]
+    snaps = [(ora.agents.copy(), ora.pots.copy(), ora.items.copy())]
+    acts = rng.choice(7, size=(K, E, A), p=[0.15, 0.15, 0.15, 0.15, 0.3, 0.03, 0.07])
+    rank = rng.integers(0, 200, size=(K, E, A))
+    rew, trunc = [], []
+    for k in range(K):
+        o, r, _, tr = ora.step(acts[k].reshape(-1).astype(np.int64), prio_override=rank[k].reshape(-1).astype(np.uint8))
+        obs.append(o); rew.append(r); trunc.append(tr)
+        snaps.append((ora.agents.copy(), ora.pots.copy(), ora.items.copy()))
+    D = obs[0].shape[1]
+    np.savez_compressed(
+        os.path.join("tests", "golden", name + ".npz"),
+        layout=np.array(rows), feature=np.array(feature), max_steps=np.array(K), spawn_cells=cells.astype(np.int16),
+        spawn_dirs=dirs.astype(np.int8), actions=acts.astype(np.int8), serve_rank=rank.astype(np.uint8),
+        obs=np.stack(obs).reshape(K + 1, E, A, D).astype(np.int8), rewards=np.stack(rew).reshape(K, E, A),
+        truncated=np.stack(trunc).reshape(K, E, A), agents=np.stack([s[0] for s in snaps]).astype(np.int16),
+        pots=np.stack([s[1] for s in snaps]).astype(np.int16), items=np.stack([s[2] for s in snaps]).astype(np.uint8))
+    print(name, "rewards earned:", float(np.stack(rew).sum()), "truncated at the end:", bool(np.stack(trunc)[-1].all()))
