@@ -230,6 +230,9 @@ def main():
     env = BatchedOvercookedVecEnv(rows, A, args.feature, E, max_steps=1000, seed=1234, env_index_base=rank * E,
                                   device=dev)
     N, D = env.N, env.D
+    if (N * D) % 4:
+        raise SystemExit(f"--envs {E} with {A} agents and {args.feature}: the rows of one step ({N} x {D} floats) must be a "
+                         "multiple of 16 bytes for the tensors of the ring to start aligned; use an env count that is a multiple of 4")
     R = 32  # distinct pre-generated action batches, cycled
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     actions = torch.randint(0, 7, (R, N), dtype=torch.int64, device=dev, generator=gen)

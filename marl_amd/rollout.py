@@ -98,12 +98,21 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     num_episodes = 0
 
     buf = agent.buffer
-    env.reset(out=buf.obs_slot(0))
     dones = torch.zeros(N, dtype=torch.float32, device=device)  # flag produced by the step BEFORE the stored row
     carry = torch.empty_like(buf.obs_slot(0))  # holds the observation that follows the last stored row
+    # The env kernel writes rows at 16-byte aligned addresses.  Row t of the rollout store starts
+    # t * N * D floats in: aligned for every t when N * D is a multiple of four (always with two or
+    # four agents); otherwise (one or three agents with an env count that is no multiple of four) the
+    # observations go through two alternating tensors of their own and are copied into the store.
+    in_place = buf.obs_slot(0).numel() % 4 == 0
+    staging = None if in_place else [torch.empty_like(carry), torch.empty_like(carry)]
 
     def slot(step):
-        return buf.obs_slot(step) if step < collect_steps else carry
+        if step >= collect_steps:
+            return carry
+        return buf.obs_slot(step) if in_place else staging[step % 2]
+
+    env.reset(out=slot(0))
 
     # With the decentralised critic and the fused sampler every producer writes straight into the
     # rollout store: the env kernel the next observation and the rewards, the sampler the
@@ -111,7 +120,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     # as float32, the done flag as float32 one row on) is kept per step in its native type and
     # converted once per rollout, and the sampler's call counter moves once per rollout: nine
     # launches fewer per step, a third of a launch-bound step.
-    direct = bool(getattr(agent, "can_act_into", lambda: False)()) and buf.max_size == collect_steps
+    direct = bool(getattr(agent, "can_act_into", lambda: False)()) and buf.max_size == collect_steps and in_place
     if direct:
         act_rows = torch.empty((collect_steps, N), dtype=torch.int64, device=device)
         term_rows = torch.empty((collect_steps, N), dtype=torch.bool, device=device)
@@ -224,7 +233,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             agent.end_direct_rollout(act_rows)
         agent.update(carry)
         # the stored rows restart at 0: the carried observation (and its done flag) becomes row 0
-        buf.obs_slot(0).copy_(carry)
+        slot(0).copy_(carry)
         if direct:
             buf.dones_buff[0].copy_(dones)
 

@@ -116,3 +116,18 @@ def test_centralised_learner_stores_the_joint_value_in_every_row(oracle_mod, fus
                 v = net.get_value(got["obs"][t], joint_obs=got["obs"][t].reshape(1, -1))
             torch.testing.assert_close(got["values"][t], v.view(1).expand(E * A), rtol=1e-4, atol=1e-5)
     assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)
+
+
+@pytest.mark.parametrize("graph_rollout", ["off", "on"])
+def test_rows_that_do_not_start_aligned_in_the_store(oracle_mod, graph_rollout):
+    """Three agents and five envs: N * D = 15 * 309 floats, so the rows of step t do not start at
+    a 16-byte boundary inside the rollout store and the driver stages observations through
+    tensors of their own; what ends up stored is the same."""
+    E, A, T, updates, max_steps = 5, 3, 9, 5, 8
+    snaps, ref, returns, _, ref_returns, _, _, _ = _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, True,
+                                                         layout="overcooked_cramped_room_v0", feature="global_obs", seed=4)
+    assert (E * A * snaps[0]["obs"].shape[-1]) % 4 != 0
+    for u, (got, want) in enumerate(zip(snaps, ref)):
+        for k in ("obs", "actions", "rewards", "dones", "next_obs"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+    assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)
