@@ -131,3 +131,30 @@ def test_rows_that_do_not_start_aligned_in_the_store(oracle_mod, graph_rollout):
         for k in ("obs", "actions", "rewards", "dones", "next_obs"):
             np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
     assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)
+
+
+def test_reference_shaped_loop_runs_on_the_host_array_env(oracle_mod):
+    """Drop-in at the vec-env boundary: the restated reference loop (host arrays in and out, as
+    agent_environment.py drives its env) runs unchanged on the numpy_io GPU env and stores what it
+    stores on the CPU oracle env."""
+    from marl_amd.env import make_env, make_vector_env
+    from marl_amd.layouts import get_layout
+    from oracle.rollout_loop import OracleDictEnv, ReplayAgent, reference_rollout_loop
+
+    E, A, T, updates, max_steps, seed = 6, 2, 10, 4, 7, 13
+    layout = "overcooked_forced_coordination_v0"
+    rng = np.random.default_rng(1)
+    acts = [rng.integers(0, 7, size=(T, E * A)) for _ in range(updates)]
+    env = make_env(A, layout, "global_obs", max_steps=max_steps)
+    vec = make_vector_env(E, env, numpy_io=True, seed=seed)
+    got_agent, logs = ReplayAgent(acts), []
+    got_returns, got_freq = reference_rollout_loop(got_agent, vec, updates, T, log=logs)
+    ora = oracle_mod.OracleVecEnv(get_layout(layout), A, "global_obs", max_steps=max_steps, num_envs=E, seed=seed)
+    ora.reset()  # make_vector_env's own reset (main.py:95)
+    want_agent = ReplayAgent(acts)
+    want_returns, want_freq = reference_rollout_loop(want_agent, OracleDictEnv(ora), updates, T)
+    assert got_returns == want_returns and got_freq == want_freq
+    for u, (got, want) in enumerate(zip(got_agent.snaps, want_agent.snaps)):
+        for k in got:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=f"update {u}: {k}")
+    assert [x[0] for x in logs].count("reset") == 1 + (T * updates) // (max_steps + 1)
