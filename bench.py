@@ -19,7 +19,8 @@ What is timed, and what the extra objects in the line mean:
     but a cache number, labelled as such;
   * `step_many`: the multi-step launch (marl_env_step_many, 32 steps per launch, usable when the
     actions are known up front as they are here), rows kept in the same ring: HBM regime;
-  * `policy_driven`: actions sampled every step from the reference-shaped fp32 MLP;
+  * `policy_driven`: actions sampled every step from the reference-shaped fp32 MLP (every rank, at
+    any N);
   * `peak_measured`: what a plain device fill / copy of the same ring reaches in this run;
   * `cpu_baseline`: the CPU restatement (oracle) on the host's cores, a bounded sample.
 """
@@ -101,8 +102,43 @@ def timed(fn, count, dev):
     return ev0.elapsed_time(ev1) * 1e3 / count
 
 
+def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max):
+    """Policy-driven rollout on every rank (MLP forward + sample + step, the policy reading what the
+    step wrote), bracketed like the timed region: barrier + synchronize on both sides, the slowest
+    rank's time counts."""
+    from marl_amd.policy import Agent
+
+    ring = store.shape[0]
+    torch.manual_seed(1)
+    policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
+                   build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
+    policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
+    env.reset(out=store[0])
+
+    def pstep(i):
+        with torch.no_grad():
+            act, _, _, _ = policy.get_action_and_value(store[i % ring])
+        env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
+
+    steps = 128
+    for i in range(16):
+        pstep(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pstep(16 + i)
+    barrier()
+    wall = reduce_max(time.perf_counter() - t0)
+    return {
+        "metric": "env agent-steps/sec (policy-driven rollout: fp32 MLP forward + sample + fused step+featurize)",
+        "value": world * N * steps / wall, "unit": "agent-steps/s", "n_gpus": world, "ms_per_step": wall / steps * 1e3,
+        "steps": steps,
+        "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs), fused categorical sampling; rows kept; "
+                  "every rank its own envs, no collective, slowest rank's wall time"}
+
+
 def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
-    """Everything in the line beyond the timed region (single GPU only)."""
+    """What rank 0 adds beyond the timed region on a single GPU."""
     out = {}
     R, ring = actions.shape[0], store.shape[0]
     frac = lambda us: N * B / us / 1e3 / HBM_PEAK_GBS  # noqa: E731
@@ -147,27 +183,6 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
         "what": f"torch fill_ of the {flat.numel() * 4 / 1e9:.1f} GB ring (write only) and a copy of one half onto the "
                 "other (read + write bytes counted), this run"}
 
-    # policy-driven rollout: MLP forward + sample + step, the policy reading what the step wrote
-    from marl_amd.policy import Agent
-
-    torch.manual_seed(1)
-    policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
-                   build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
-    policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
-    env.reset(out=store[0])
-
-    def pstep(i):
-        with torch.no_grad():
-            act, _, _, _ = policy.get_action_and_value(store[i % ring])
-        env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
-
-    for i in range(16):
-        pstep(i)
-    us_p = timed(lambda i: pstep(16 + i), 128, dev)
-    out["policy_driven"] = {
-        "metric": "env agent-steps/sec (policy-driven rollout: fp32 MLP forward + sample + fused step+featurize)",
-        "value": N / us_p * 1e6, "unit": "agent-steps/s", "ms_per_step": us_p / 1e3, "steps": 128,
-        "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs), fused categorical sampling; rows kept"}
     return out
 
 
@@ -296,10 +311,19 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
 
-    if group is not None:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    def reduce_max(*vals):
+        if group is None:
+            return vals if len(vals) > 1 else vals[0]
+        tt = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms = tt.tolist()
+        out = tt.tolist()
+        return out if len(out) > 1 else out[0]
+
+    wall, dev_ms = reduce_max(wall, dev_ms)
+    # north star: random-action AND policy-driven rates at every GPU count
+    policy_line = None
+    if policy is None and not args.no_extra_legs:
+        policy_line = policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max)
 
     if rank == 0:
         B = algorithmic_bytes_per_agent_step(D, env.state_words, A, actions.element_size())
@@ -353,6 +377,8 @@ def main():
             out["roofline"]["peak_measured"] = pm
             out["roofline"]["frac_of_measured_fill"] = achieved / pm["fill_GBps"]
             out.update(legs)
+        if policy_line is not None:
+            out["policy_driven"] = policy_line
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234)
         print(json.dumps(out), flush=True)

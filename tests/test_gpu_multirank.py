@@ -61,3 +61,7 @@ def test_two_rank_bench_reports_whole_job_throughput():
     # value counts both ranks' rows
     assert abs(out["value"] - 2 * 4096 * 2 * 64 / (out["ms_per_step"] * 1e-3 * 64)) / out["value"] < 1e-6
     assert "cpu_baseline" not in out
+    # the policy-driven rate is reported at every rank count, again over both ranks' rows
+    pd = out["policy_driven"]
+    assert pd["n_gpus"] == 2
+    assert abs(pd["value"] - 2 * 4096 * 2 * pd["steps"] / (pd["ms_per_step"] * 1e-3 * pd["steps"])) / pd["value"] < 1e-6

@@ -65,7 +65,9 @@ def test_training_collectives_run_over_rccl(tmp_path, algorithm, graph_rollout):
 
 def test_bench_runs_through_the_nccl_branch():
     r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8", "--envs", "4096",
-                 "--no-cpu-baseline", "--no-extra-legs"], {})
+                 "--no-cpu-baseline"], {})
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["process_group"] == "nccl"
+    # the policy-driven leg takes its maximum over ranks through the same process group
+    assert out["policy_driven"]["n_gpus"] == 1 and out["policy_driven"]["value"] > 0
