@@ -9,7 +9,7 @@ SAN="-Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -g"
 if [ "$1" = build ]; then
   mkdir -p $OUT
   make -s -C marl_amd/csrc -j4 HIPCC="/opt/rocm/bin/hipcc $SAN" OBJDIR=../../build/asan_obj OUT=../../$OUT/libmarl_amd_asan.so
-  /opt/rocm/bin/hipcc $SAN -O1 -std=c++17 --offload-arch=gfx950 profiles/diag/capi_host_asan.cpp -o $OUT/capi_host_asan \
+  /opt/rocm/bin/hipcc $SAN -O1 -std=c++17 --offload-arch=gfx950 tests/native/capi_driver.cpp -o $OUT/capi_host_asan \
     -L$OUT -lmarl_amd_asan -Wl,-rpath,'$ORIGIN'
   ls -la $OUT
 else

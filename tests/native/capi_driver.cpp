@@ -1,8 +1,10 @@
-// Host-side AddressSanitizer pass over the C ABI (device code is not instrumented): every entry
-// point of include/marl_amd.h is called from plain C++ for all agent counts, feature sets and a
-// few layouts (odd env counts included), then the argument checks are driven through their
-// failure paths.  Built by profiles/diag/capi_host_asan.sh; prints one line per stage and
-// "capi host pass: ok" at the end; ASan aborts the process on the first host memory error.
+// The C ABI used from plain C++, no Python and no torch in the process: every entry point of
+// include/marl_amd.h is called for all agent counts, feature sets and a few layouts (odd env
+// counts included), then the argument checks are driven through their failure paths.  Prints one
+// line per stage and "capi host pass: ok" at the end.  Built by tests/native/Makefile (run by the
+// GPU suite, tests/test_gpu_capi_native.py) and, with AddressSanitizer on the host code of driver
+// and library, by profiles/diag/capi_host_asan.sh (ASan ends the process at the first host
+// memory error; device code is not instrumented).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
