@@ -19,6 +19,9 @@ What is timed, and what the extra objects in the line mean:
     but a cache number, labelled as such;
   * `step_many`: the multi-step launch (marl_env_step_many, 32 steps per launch, usable when the
     actions are known up front as they are here), rows kept in the same ring: HBM regime;
+  * `two_shards`: the batch as two half-batch env handles on two streams, single-step launches
+    replayed from one hipGraph without a join between steps (one shard simulates while the other
+    streams its rows), rows kept: HBM regime;
   * `policy_driven`: actions sampled every step from the reference-shaped fp32 MLP (every rank, at
     any N);
   * `peak_measured`: what a plain device fill / copy of the same ring reaches in this run;
@@ -137,7 +140,49 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
                   "every rank its own envs, no collective, slowest rank's wall time"}
 
 
-def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
+def two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E):
+    from marl_amd.env import BatchedOvercookedVecEnv
+
+    ring, half = store.shape[0], N // 2
+    side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    shards = []
+    for k in range(2):
+        e = BatchedOvercookedVecEnv(env.layout_rows, A, env.feature, E // 2, max_steps=env.max_steps, seed=1234,
+                                    env_index_base=rank * E + k * (E // 2), device=dev)
+        # every shard writes its own half of each tensor of the ring, reads its half of the actions
+        obs = [store[i][k * half:(k + 1) * half] for i in range(ring)]
+        bufs = (torch.empty(half, dtype=torch.float32, device=dev), torch.empty(half, dtype=torch.bool, device=dev),
+                torch.empty(half, dtype=torch.bool, device=dev))
+        acts = actions[:, k * half:(k + 1) * half].contiguous()
+        e.reset(out=obs[0])
+        shards.append((e, obs, bufs, acts))
+
+    def chain(k):
+        e, obs, (rew, term, trunc), acts = shards[k]
+        for i in range(ring):
+            e.step_into(acts[i % acts.shape[0]], obs[(i + 1) % ring], rew, term, trunc)
+
+    chain(0), chain(1)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream(dev)
+        for k in range(2):
+            side[k].wait_stream(main)
+            with torch.cuda.stream(side[k]):
+                chain(k)
+        for k in range(2):
+            main.wait_stream(side[k])
+    g.replay()
+    reps = 16
+    us = timed(lambda i: g.replay(), reps, dev) / ring
+    return {"regime": f"two shards of {E // 2} envs (env handles of their own) on two streams, single-step launches, one hipGraph "
+                      f"of {ring} steps with a branch per shard and no join between steps; every step's rows kept: HBM",
+            "bound": "hbm", "us_per_step": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
+            "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
+
+
+def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E):
     """What rank 0 adds beyond the timed region on a single GPU."""
     out = {}
     R, ring = actions.shape[0], store.shape[0]
@@ -168,6 +213,12 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A):
             "bound": "hbm", "steps_per_launch": ring, "us_per_step": us_m, "value": N / us_m * 1e6,
             "achieved": N * B / us_m / 1e3, "unit": "GB/s", "frac": frac(us_m)}
         del rew_k, te_k, tr_k
+
+    # two half-batch shards (env handles of their own) on two streams, single-step launches, rows
+    # kept; one hipGraph with a branch per shard and no join between steps, so the shards drift out of
+    # phase and one shard's simulation runs while the other streams its rows
+    if E % 2 == 0 and ((N // 2) * D) % 4 == 0:
+        out["two_shards"] = two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E)
 
     # what plain device writes / copies of the same memory reach in this run
     flat = store.view(-1)
@@ -372,7 +423,7 @@ def main():
             # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
             out["roofline"] = None
         if world == 1 and policy is None and not args.no_extra_legs:
-            legs = extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A)
+            legs = extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E)
             pm = legs.pop("peak_measured")
             out["roofline"]["peak_measured"] = pm
             out["roofline"]["frac_of_measured_fill"] = achieved / pm["fill_GBps"]
