@@ -182,25 +182,41 @@ def two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E):
             "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
 
 
+def guarded(out, name, fn):
+    """An extra leg that raises must not take the headline with it: its entry then carries the error."""
+    try:
+        val = fn()
+        if val is not None:
+            out[name] = val
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        out[name] = {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E):
     """What rank 0 adds beyond the timed region on a single GPU."""
     out = {}
     R, ring = actions.shape[0], store.shape[0]
     frac = lambda us: N * B / us / 1e3 / HBM_PEAK_GBS  # noqa: E731
 
-    # two alternating tensors: the rows never have to leave the last-level cache
-    for i in range(64):
-        env.step_into(actions[i % R], store[i % 2], rew, term, trunc)
-    us = timed(lambda i: env.step_into(actions[i % R], store[i % 2], rew, term, trunc), 1024, dev)
-    out["llc_resident"] = {
-        "regime": (f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows stay in the 256 MiB last-level cache and are overwritten "
-                   "there; cache-resident store rate, NOT HBM bandwidth") if 2 * N * D * 4 <= (256 << 20) else
-                  f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows, more than the 256 MiB last-level cache holds: they drain to HBM",
-        "bound": "llc" if 2 * N * D * 4 <= (256 << 20) else "hbm", "us_per_launch": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
-        "frac_of_hbm_spec": frac(us)}
+    def llc_leg():
+        # two alternating tensors: the rows never have to leave the last-level cache
+        for i in range(64):
+            env.step_into(actions[i % R], store[i % 2], rew, term, trunc)
+        us = timed(lambda i: env.step_into(actions[i % R], store[i % 2], rew, term, trunc), 1024, dev)
+        return {
+            "regime": (f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows stay in the 256 MiB last-level cache and are overwritten "
+                       "there; cache-resident store rate, NOT HBM bandwidth") if 2 * N * D * 4 <= (256 << 20) else
+                      f"obs_ring=2: {2 * N * D * 4 / 1e6:.0f} MB of rows, more than the 256 MiB last-level cache holds: they drain to HBM",
+            "bound": "llc" if 2 * N * D * 4 <= (256 << 20) else "hbm", "us_per_launch": us, "value": N / us * 1e6,
+            "achieved": N * B / us / 1e3, "unit": "GB/s", "frac_of_hbm_spec": frac(us)}
 
-    # the multi-step launch, rows kept
-    if (N * D) % 4 == 0 and R >= ring:
+    def step_many_leg():
+        # the multi-step launch, rows kept
+        if (N * D) % 4 != 0 or R < ring:
+            return None
         rew_k = torch.empty((ring, N), dtype=torch.float32, device=dev)
         te_k = torch.empty((ring, N), dtype=torch.bool, device=dev)
         tr_k = torch.empty_like(te_k)
@@ -208,32 +224,38 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E):
         env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
         reps = 16
         us_m = timed(lambda i: env.step_many_into(acts_k, store, rew_k, te_k, tr_k), reps, dev) / ring
-        out["step_many"] = {
+        return {
             "regime": f"marl_env_step_many, {ring} steps per launch, every step's rows kept (obs_ring={ring}): HBM",
             "bound": "hbm", "steps_per_launch": ring, "us_per_step": us_m, "value": N / us_m * 1e6,
             "achieved": N * B / us_m / 1e3, "unit": "GB/s", "frac": frac(us_m)}
-        del rew_k, te_k, tr_k
 
-    # two half-batch shards (env handles of their own) on two streams, single-step launches, rows
-    # kept; one hipGraph with a branch per shard and no join between steps, so the shards drift out of
-    # phase and one shard's simulation runs while the other streams its rows
-    if E % 2 == 0 and ((N // 2) * D) % 4 == 0:
-        out["two_shards"] = two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E)
+    def shards_leg():
+        # two half-batch shards (env handles of their own) on two streams, single-step launches, rows
+        # kept; one hipGraph with a branch per shard and no join between steps, so the shards drift out
+        # of phase and one shard's simulation runs while the other streams its rows
+        if E % 2 != 0 or ((N // 2) * D) % 4 != 0:
+            return None
+        return two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E)
 
-    # what plain device writes / copies of the same memory reach in this run
-    flat = store.view(-1)
-    for _ in range(2):
-        flat.fill_(1.0)
-    us_fill = timed(lambda i: flat.fill_(float(i)), 8, dev)
-    half = flat.numel() // 2
-    a, b = flat[:half], flat[half:2 * half]
-    b.copy_(a)
-    us_copy = timed(lambda i: b.copy_(a), 8, dev)
-    out["peak_measured"] = {
-        "fill_GBps": flat.numel() * 4 / us_fill / 1e3, "copy_GBps": 2 * half * 4 / us_copy / 1e3,
-        "what": f"torch fill_ of the {flat.numel() * 4 / 1e9:.1f} GB ring (write only) and a copy of one half onto the "
-                "other (read + write bytes counted), this run"}
+    def peak_leg():
+        # what plain device writes / copies of the same memory reach in this run
+        flat = store.view(-1)
+        for _ in range(2):
+            flat.fill_(1.0)
+        us_fill = timed(lambda i: flat.fill_(float(i)), 8, dev)
+        half = flat.numel() // 2
+        a, b = flat[:half], flat[half:2 * half]
+        b.copy_(a)
+        us_copy = timed(lambda i: b.copy_(a), 8, dev)
+        return {
+            "fill_GBps": flat.numel() * 4 / us_fill / 1e3, "copy_GBps": 2 * half * 4 / us_copy / 1e3,
+            "what": f"torch fill_ of the {flat.numel() * 4 / 1e9:.1f} GB ring (write only) and a copy of one half onto the "
+                    "other (read + write bytes counted), this run"}
 
+    guarded(out, "llc_resident", llc_leg)
+    guarded(out, "step_many", step_many_leg)
+    guarded(out, "two_shards", shards_leg)
+    guarded(out, "peak_measured", peak_leg)
     return out
 
 
@@ -374,7 +396,12 @@ def main():
     # north star: random-action AND policy-driven rates at every GPU count
     policy_line = None
     if policy is None and not args.no_extra_legs:
-        policy_line = policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max)
+        if world == 1:
+            holder = {}
+            guarded(holder, "policy_driven", lambda: policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max))
+            policy_line = holder.get("policy_driven")
+        else:  # several ranks: a rank that fails must end the job, not leave the others at a barrier
+            policy_line = policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max)
 
     if rank == 0:
         B = algorithmic_bytes_per_agent_step(D, env.state_words, A, actions.element_size())
@@ -424,14 +451,15 @@ def main():
             out["roofline"] = None
         if world == 1 and policy is None and not args.no_extra_legs:
             legs = extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E)
-            pm = legs.pop("peak_measured")
+            pm = legs.pop("peak_measured", None)
             out["roofline"]["peak_measured"] = pm
-            out["roofline"]["frac_of_measured_fill"] = achieved / pm["fill_GBps"]
+            if pm and "fill_GBps" in pm:
+                out["roofline"]["frac_of_measured_fill"] = achieved / pm["fill_GBps"]
             out.update(legs)
         if policy_line is not None:
             out["policy_driven"] = policy_line
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rows, A, args.feature, E, 1234)
+            guarded(out, "cpu_baseline", lambda: cpu_baseline(rows, A, args.feature, E, 1234))
         print(json.dumps(out), flush=True)
     if group is not None:
         dist.destroy_process_group()
