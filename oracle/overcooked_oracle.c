@@ -83,6 +83,12 @@ int oc_layout_init(oc_layout *L, const char *const *rows, int H, int num_agents,
             }
         }
     }
+    /* every agent needs a start cell of its own: a '+' cell each when the layout names spawn points,
+     * any floor cell otherwise */
+    int nfloor = 0;
+    for (int c = 0; c < H * W; ++c) nfloor += L->type[c] == OC_FLOOR;
+    if (L->nspawn > 0 && L->nspawn < num_agents) return -7;
+    if (nfloor < num_agents) return -8;
     L->block_dim = block_dim_for(feature, num_agents);
     if (L->block_dim < 0) return -6;
     L->obs_dim = (feature == OC_FEAT_GLOBAL) ? num_agents * L->block_dim : L->block_dim;

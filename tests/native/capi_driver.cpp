@@ -168,6 +168,7 @@ int main() {
     EXPECT(marl_env_create(&env, RAGGED, 4, 2, 0, 10, 4, 1, 0, 0) == MARL_ERR_LAYOUT);
     EXPECT(marl_env_create(&env, UNKNOWN, 4, 2, 0, 10, 4, 1, 0, 0) == MARL_ERR_LAYOUT);
     EXPECT(marl_env_create(&env, NOFLOOR, 3, 2, 0, 10, 4, 1, 0, 0) != MARL_OK);
+    EXPECT(marl_env_create(&env, FORCED, 7, 3, 0, 10, 4, 1, 0, 0) == MARL_ERR_LAYOUT);  // two '+' cells, three agents
     EXPECT(marl_env_create(&env, CRAMPED, 6, 5, 0, 10, 4, 1, 0, 0) == MARL_ERR_INVALID);
     EXPECT(marl_env_create(&env, CRAMPED, 6, 0, 0, 10, 4, 1, 0, 0) == MARL_ERR_INVALID);
     EXPECT(marl_env_create(&env, CRAMPED, 6, 2, 9, 10, 4, 1, 0, 0) == MARL_ERR_INVALID);

@@ -318,6 +318,21 @@ def test_single_env_dict_api_without_auto_reset(oracle_mod):
     assert ora.misc[0, 0] == 15
 
 
+def test_layouts_without_a_start_cell_per_agent_are_refused(oracle_mod):
+    """forced_coordination names two spawn cells: a third agent has nowhere to start.  Library and
+    oracle both refuse at creation instead of stacking agents on one cell."""
+    from marl_amd._lib import MarlAmdError
+    from marl_amd.env import BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_forced_coordination_v0")
+    with pytest.raises(MarlAmdError, match="spawn"):
+        BatchedOvercookedVecEnv(rows, 3, "global_obs", 4)
+    with pytest.raises(ValueError):
+        oracle_mod.OracleVecEnv(rows, 3, "global_obs", num_envs=4)
+    with pytest.raises(MarlAmdError):
+        BatchedOvercookedVecEnv(["####", "#C #", "####"], 2, "global_obs", 4)  # one floor cell, two agents
+
+
 def test_determinism_and_reseeding():
     from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
 
