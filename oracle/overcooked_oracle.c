@@ -87,6 +87,10 @@ int oc_layout_init(oc_layout *L, const char *const *rows, int H, int num_agents,
      * any floor cell otherwise */
     int nfloor = 0;
     for (int c = 0; c < H * W; ++c) nfloor += L->type[c] == OC_FLOOR;
+    /* the grid must be walled in: no floor on its border (every registered layout is) */
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c)
+            if ((r == 0 || r == H - 1 || c == 0 || c == W - 1) && L->type[r * W + c] == OC_FLOOR) return -9;
     if (L->nspawn > 0 && L->nspawn < num_agents) return -7;
     if (nfloor < num_agents) return -8;
     L->block_dim = block_dim_for(feature, num_agents);

@@ -320,7 +320,8 @@ def test_single_env_dict_api_without_auto_reset(oracle_mod):
 
 def test_layouts_without_a_start_cell_per_agent_are_refused(oracle_mod):
     """forced_coordination names two spawn cells: a third agent has nowhere to start.  Library and
-    oracle both refuse at creation instead of stacking agents on one cell."""
+    oracle both refuse at creation instead of stacking agents on one cell; both also refuse a grid
+    with floor on its border."""
     from marl_amd._lib import MarlAmdError
     from marl_amd.env import BatchedOvercookedVecEnv
 
@@ -331,6 +332,12 @@ def test_layouts_without_a_start_cell_per_agent_are_refused(oracle_mod):
         oracle_mod.OracleVecEnv(rows, 3, "global_obs", num_envs=4)
     with pytest.raises(MarlAmdError):
         BatchedOvercookedVecEnv(["####", "#C #", "####"], 2, "global_obs", 4)  # one floor cell, two agents
+    # floor on the border of the grid (nothing beyond it): every registered layout is walled in
+    open_rows = ["  O  ", " CUC ", "     ", "=   @"]
+    with pytest.raises(MarlAmdError, match="enclosed"):
+        BatchedOvercookedVecEnv(open_rows, 2, "global_obs", 4)
+    with pytest.raises(ValueError):
+        oracle_mod.OracleVecEnv(open_rows, 2, "global_obs", num_envs=4)
 
 
 def test_determinism_and_reseeding():
