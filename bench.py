@@ -10,6 +10,7 @@ torch.distributed.run, one rank per GPU) every rank steps its own 65,536 envs (w
 RNG keys are offset by rank so the job equals one big env batch); there is no data-path
 collective.  Rank 0 prints one JSON line.
 
+Before the W warm-up steps the process steps the envs untimed for --spinup-ms (300 ms; clocks).
 What is timed, and what the extra objects in the line mean:
   * the timed K steps write every step's observation rows into their own tensor of a ring of 32
     (3.4 GB), as a rollout store keeps them: the rows have to drain to HBM, and `value`, `roofline`
@@ -281,6 +282,9 @@ def main():
                     help="observation tensors the timed steps cycle through (32: every step's rows are kept like in a "
                          "rollout store and drain to HBM; 2: the next step overwrites the rows the consumer has just "
                          "read, they never leave the last-level cache)")
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="untimed env steps for this long before the warm-up steps, so that a short run does not measure "
+                         "the GPU's power-saving state (0 = none)")
     ap.add_argument("--mode", choices=["random", "policy"], default="random",
                     help="random: pre-generated uniform actions (headline); policy: the timed steps sample their actions "
                          "from the reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm)")
@@ -326,6 +330,7 @@ def main():
     actions = torch.randint(0, 7, (R, N), dtype=torch.int64, device=dev, generator=gen)
     RING = int(max(2, min(args.obs_ring, (8 << 30) // (N * D * 4))))  # at most 8 GB of rows
     store = torch.empty((RING, N, D), dtype=torch.float32, device=dev)
+    store.zero_()  # a rollout store is written rollout after rollout: no timed step is the first touch of its rows
     rew = torch.empty(N, dtype=torch.float32, device=dev)
     term = torch.empty(N, dtype=torch.bool, device=dev)
     trunc = torch.empty(N, dtype=torch.bool, device=dev)
@@ -349,6 +354,19 @@ def main():
                 act, _, _, _ = policy.get_action_and_value(store[i % RING])
             env.step_into(act, store[(i + 1) % RING], rew, term, trunc)
 
+    # Device spin-up, before the W warm-up steps and outside every measurement: a run of a few dozen
+    # launches (--steps 20 --warmup 5 is 0.6 ms of GPU work) otherwise starts timing on a GPU that has
+    # been busy for a millisecond since its context was created.  Measured with those flags: 22.5 us per
+    # launch after 300 ms of untimed steps, 22.6-23.2 us without.
+    if args.spinup_ms > 0:
+        t_end = time.perf_counter() + args.spinup_ms * 1e-3
+        i = 0
+        while time.perf_counter() < t_end:
+            for _ in range(64):
+                env.step_into(actions[i % R], store[(i + 1) % RING], rew, term, trunc)
+                i += 1
+            torch.cuda.synchronize()
+        env.reset(out=store[0])
     for i in range(args.warmup):
         eager(i)
     torch.cuda.synchronize()
