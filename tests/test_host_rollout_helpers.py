@@ -32,3 +32,15 @@ def test_bench_counts_the_cores_this_process_may_use(monkeypatch):
     threads, total, affinity, share = bench.host_threads()
     assert share == 0 and threads == min(total, affinity)
     assert bench.algorithmic_bytes_per_agent_step(202, 5, 2, 8) == 842.0
+
+
+def test_a_failing_bench_leg_reports_its_error_and_spares_the_line(capsys):
+    import bench
+
+    out = {"value": 1.0}
+    bench.guarded(out, "good", lambda: {"value": 2.0})
+    bench.guarded(out, "skipped", lambda: None)
+    bench.guarded(out, "bad", lambda: 1 / 0)
+    assert out["good"] == {"value": 2.0} and "skipped" not in out
+    assert out["bad"]["error"].startswith("ZeroDivisionError") and out["value"] == 1.0
+    assert "ZeroDivisionError" in capsys.readouterr().err  # the traceback still goes to stderr
