@@ -119,9 +119,14 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
     policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
     env.reset(out=store[0])
 
+    # the rollout half of act() as the trainer's rollouts run it (`Agent.rollout_step`): both heads from
+    # one GEMM, actions, log-probabilities and values written in place
+    act = torch.empty(N, dtype=torch.int64, device=dev)
+    logp = torch.empty(N, dtype=torch.float32, device=dev)
+    val = torch.empty(N, dtype=torch.float32, device=dev)
+
     def pstep(i):
-        with torch.no_grad():
-            act, _, _, _ = policy.get_action_and_value(store[i % ring])
+        policy.rollout_step(store[i % ring], logp, val, actions_out=act)
         env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
 
     steps = 128
@@ -137,7 +142,7 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
         "metric": "env agent-steps/sec (policy-driven rollout: fp32 MLP forward + sample + fused step+featurize)",
         "value": world * N * steps / wall, "unit": "agent-steps/s", "n_gpus": world, "ms_per_step": wall / steps * 1e3,
         "steps": steps,
-        "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs), fused categorical sampling; rows kept; "
+        "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs, both heads in one), fused categorical sampling; rows kept; "
                   "every rank its own envs, no collective, slowest rank's wall time"}
 
 
