@@ -349,15 +349,17 @@ def main():
         policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
                        build_centralised=False).to(dev)
         policy.use_fused_sampling(1234, row_index_base=rank * N)
+        p_act = torch.empty(N, dtype=torch.int64, device=dev)
+        p_logp = torch.empty(N, dtype=torch.float32, device=dev)
+        p_val = torch.empty(N, dtype=torch.float32, device=dev)
 
     def eager(i):
         # step i reads (policy mode) the rows in slot i and writes slot i + 1; slot 0 holds the reset's rows
         if policy is None:
             env.step_into(actions[i % R], store[(i + 1) % RING], rew, term, trunc)
         else:
-            with torch.no_grad():
-                act, _, _, _ = policy.get_action_and_value(store[i % RING])
-            env.step_into(act, store[(i + 1) % RING], rew, term, trunc)
+            policy.rollout_step(store[i % RING], p_logp, p_val, actions_out=p_act)
+            env.step_into(p_act, store[(i + 1) % RING], rew, term, trunc)
 
     # Device spin-up, before the W warm-up steps and outside every measurement: a run of a few dozen
     # launches (--steps 20 --warmup 5 is 0.6 ms of GPU work) otherwise starts timing on a GPU that has
