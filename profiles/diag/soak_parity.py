@@ -2,7 +2,7 @@
 evidence run, too long for the test suite): every step compares all observation rows, rewards and
 flags, every 50th step and every restart the exported state.
 
-    python profiles/diag/soak_parity.py [steps]
+    python profiles/diag/soak_parity.py [steps] [first case] [last case + 1]
 """
 import os
 import sys
@@ -26,6 +26,13 @@ CASES = [
     ("overcooked_coordination_ring_v0", 4, "local_obs", 16384, 300),
     ("large_overcooked_layout", 4, "global_obs", 8192, 350),
     ("overcooked_coordination_ring_v0", 3, "global_obs", 16384, 200),
+    # second batch: one agent, the remaining feature sets and layouts
+    ("overcooked_cramped_room_v0", 1, "global_obs", 32768, 150),
+    ("overcooked_asymmetric_advantages_v0", 2, "Minimal_spatial", 32768, 250),
+    ("overcooked_counter_circuit_v0", 2, "Minimal_spatial_other_agent_aware", 32768, 300),
+    ("overcooked_cramped_room_v0", 4, "only_direction", 16384, 120),
+    ("overcooked_asymmetric_advantages_v0", 3, "local_obs", 16384, 200),
+    ("overcooked_forced_coordination_v0", 2, "global_obs", 65536, 333),
 ]
 
 
@@ -34,7 +41,9 @@ def main():
     oracle.build()
     threads = min(16, len(os.sched_getaffinity(0)))
     dev = torch.device("cuda", 0)
-    for layout, A, feature, E, max_steps in CASES:
+    lo = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    hi = int(sys.argv[3]) if len(sys.argv) > 3 else len(CASES)
+    for layout, A, feature, E, max_steps in CASES[lo:hi]:
         rows = get_layout(layout)
         gpu = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=max_steps, seed=99, env_index_base=12345, device=dev)
         ora = oracle.OracleVecEnv(rows, A, feature, max_steps=max_steps, num_envs=E, seed=99, env_index_base=12345,
