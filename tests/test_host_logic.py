@@ -127,3 +127,19 @@ def test_train_cli_rejects_out_of_scope_algorithms():
     assert (args.num_agents, args.num_envs, args.num_steps, args.num_minibatches) == (4, 8, 128, 4)
     assert (args.gamma, args.lam, args.lr, args.ppo_epoch, args.clip_param) == (0.99, 0.95, 1e-4, 10, 0.2)
     assert (args.value_loss_coef, args.entropy_coef, args.max_grad_norm) == (0.5, 0.01, 0.5)
+
+
+def test_every_environment_variable_the_code_reads_is_listed_in_the_readme():
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py")]
+    for pat in ("marl_amd/*.py", "marl_amd/agents/*.py", "marl_amd/csrc/*.hip", "marl_amd/csrc/*.inc", "marl_amd/csrc/*.h"):
+        files += glob.glob(os.path.join(root, pat))
+    used = set()
+    for f in files:
+        used |= set(re.findall(r"MARL_AMD_[A-Z_]+", open(f).read()))
+    listed = set(re.findall(r"MARL_AMD_[A-Z_]+", open(os.path.join(root, "README.md")).read()))
+    assert used and used <= listed, f"not in README.md: {sorted(used - listed)}"
