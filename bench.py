@@ -61,14 +61,17 @@ def host_threads():
     return max(threads, 1), total, affinity, share
 
 
-def cpu_baseline(layout_rows, A, feature, E, seed):
+def cpu_baseline(layout_rows, A, feature, E, seed, single_thread=False, budget_s=15.0):
     """Time the CPU oracle (plain-C restatement, OpenMP over envs) on a bounded sample of the
-    same workload.  Reported as a baseline only."""
+    same workload: on every core this job may use, or (single_thread) on one.  Reported as a
+    baseline only."""
     import numpy as np
 
     import oracle
 
     threads, total, affinity, share = host_threads()
+    if single_thread:
+        threads, E = 1, min(E, 4096)  # one thread needs no more envs than keep it busy for a step
     oracle.build()
     env = oracle.OracleVecEnv(layout_rows, A, feature, max_steps=1000, num_envs=E, seed=seed, nthreads=threads)
     env.reset()
@@ -78,7 +81,7 @@ def cpu_baseline(layout_rows, A, feature, E, seed):
     for i in range(4):
         env.step(acts[i % 8])
     per = (time.perf_counter() - t0) / 4
-    steps = int(max(8, min(6000, 15.0 / max(per, 1e-6))))  # about 15 s of host work
+    steps = int(max(8, min(6000, budget_s / max(per, 1e-6))))  # about budget_s seconds of host work
     t0 = time.perf_counter()
     for i in range(steps):
         env.step(acts[i % 8])
@@ -90,8 +93,33 @@ def cpu_baseline(layout_rows, A, feature, E, seed):
         "kind": "port",
         "host": {"os_cpu_count": total, "sched_affinity": affinity, "OMP_NUM_THREADS": share or None},
         "sample": f"{steps} steps x {E} envs x {A} agents, same layout/features/actions distribution, "
-                  f"CPU restatement (not cogrid) on {threads} OpenMP threads = every core this job may use, {dt:.1f} s",
+                  f"CPU restatement (not cogrid) on {threads} OpenMP thread(s)"
+                  + ("" if single_thread else " = every core this job may use") + f", {dt:.1f} s",
     }
+
+
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def rank_launch_command(n, argv, port):
+    """The command `python bench.py --gpus N ...` turns itself into: one rank per GPU under
+    torch.distributed.run, rendezvous on the loopback address."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(n, argv):
+    """Run the N ranks as a child process tree and hand back its exit code.  Called before anything
+    in this process has initialised the GPU; the child's stdout (rank 0's JSON line) and stderr pass
+    straight through."""
+    import subprocess
+
+    return subprocess.run(rank_launch_command(n, argv, free_port())).returncode
 
 
 def timed(fn, count, dev):
@@ -258,6 +286,24 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E):
             "what": f"torch fill_ of the {flat.numel() * 4 / 1e9:.1f} GB ring (write only) and a copy of one half onto the "
                     "other (read + write bytes counted), this run"}
 
+    def launch_dist_leg():
+        # distribution of the single-step launch time, rows kept: an event between every two launches
+        # (the events cost a little themselves, so the median sits slightly above roofline.us_per_launch)
+        n = 1024
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        for i in range(ring):
+            env.step_into(actions[i % R], store[(i + 1) % ring], rew, term, trunc)
+        torch.cuda.synchronize(dev)
+        evs[0].record()
+        for i in range(n):
+            env.step_into(actions[i % R], store[(i + 1) % ring], rew, term, trunc)
+            evs[i + 1].record()
+        torch.cuda.synchronize(dev)
+        us = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(n))
+        return {"n": n, "min": us[0], "p10": us[n // 10], "median": us[n // 2], "p90": us[n * 9 // 10], "p99": us[n * 99 // 100],
+                "max": us[-1], "unit": "us per launch, event to event on the launch stream"}
+
+    guarded(out, "launch_time_us", launch_dist_leg)
     guarded(out, "llc_resident", llc_leg)
     guarded(out, "step_many", step_many_leg)
     guarded(out, "two_shards", shards_leg)
@@ -290,6 +336,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed env steps for this long before the warm-up steps, so that a short run does not measure "
                          "the GPU's power-saving state (0 = none)")
+    ap.add_argument("--single-gpu-value", type=float, default=None,
+                    help="agent-steps/s of the same command at --gpus 1: adds scaling_efficiency = value / (N x this) to the line")
     ap.add_argument("--mode", choices=["random", "policy"], default="random",
                     help="random: pre-generated uniform actions (headline); policy: the timed steps sample their actions "
                          "from the reference-shaped MLP (obs->512->256->7/1, fp32, PyTorch-ROCm)")
@@ -299,11 +347,15 @@ def main():
     elif args.config == 5:
         args.layout, args.agents, args.feature, args.envs = "overcooked_coordination_ring_v0", 4, "local_obs", 65536
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as `python bench.py --gpus N`: this process becomes the launcher and never touches
+        # the GPU; the ranks are fresh children (one per GPU) of torch.distributed.run
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     backend = os.environ.get("MARL_AMD_DIST_BACKEND", "nccl")  # gloo: several ranks on one GPU (rehearsal only)
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
@@ -417,7 +469,20 @@ def main():
         out = tt.tolist()
         return out if len(out) > 1 else out[0]
 
+    my_dev_ms = dev_ms
     wall, dev_ms = reduce_max(wall, dev_ms)
+    ranks_seen, per_rank_us = 1, [my_dev_ms * 1e3 / args.steps]
+    if group is not None:
+        # proof that the collective library saw every rank: a SUM all-reduce of ones (on the device
+        # under RCCL) and the per-rank launch times gathered to everybody
+        cdev = dev if backend == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.float32, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        mine = torch.tensor([my_dev_ms * 1e3 / args.steps], dtype=torch.float64, device=cdev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_us = [float(g.item()) for g in gathered]
     # north star: random-action AND policy-driven rates at every GPU count
     policy_line = None
     if policy is None and not args.no_extra_legs:
@@ -459,7 +524,11 @@ def main():
                                    + (f"every step's rows kept (ring of {RING} observation tensors, {RING * N * D * 4 / 1e9:.1f} GB)"
                                       if kept else f"{RING} alternating observation tensors (cache resident)"),
                        "launch": "hipGraph of 32 steps" if graph is not None else "eager",
-                       "obs_ring": RING, "process_group": group},
+                       "obs_ring": RING, "process_group": group, "spinup_ms": args.spinup_ms,
+                       "world_size": dist.get_world_size() if group is not None else 1,
+                       "all_reduce_ranks": ranks_seen,
+                       "rccl_ranks": ranks_seen if group == "nccl" else None,
+                       "envs_total": world * E},
             "roofline": {"bound": "hbm" if kept else "llc",
                          "regime": ("rows kept: they drain to HBM while they are written" if kept else
                                     "rows overwritten inside the 256 MiB last-level cache: a cache number, not HBM bandwidth"),
@@ -469,8 +538,14 @@ def main():
                          "profiles/traffic.json: rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch) of an earlier "
                          "run of this command, not measured in this run",
                          "bytes_per_agent_step": B, "kernel": f"env_kernel<{A} agents, {args.feature}> (step+featurize)",
-                         "us_per_launch": launch_s * 1e6},
+                         "us_per_launch": launch_s * 1e6,
+                         "us_per_launch_per_rank": per_rank_us,
+                         "which_rank": "slowest rank (max over ranks of the HIP-event time)" if world > 1 else "rank 0",
+                         # by the clock `value` uses (host wall time around the timed region, launch gaps included)
+                         "frac_wall": N * B / (wall / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        if args.single_gpu_value:
+            out["scaling_efficiency"] = out["value"] / (world * args.single_gpu_value)
         if policy is not None:
             # the per-step time now contains the MLP forward pass: no single-kernel roofline applies
             out["roofline"] = None
@@ -485,6 +560,7 @@ def main():
             out["policy_driven"] = policy_line
         if world == 1 and not args.no_cpu_baseline:
             guarded(out, "cpu_baseline", lambda: cpu_baseline(rows, A, args.feature, E, 1234))
+            guarded(out, "cpu_baseline_1t", lambda: cpu_baseline(rows, A, args.feature, E, 1234, single_thread=True, budget_s=3.0))
         print(json.dumps(out), flush=True)
     if group is not None:
         dist.destroy_process_group()

@@ -65,3 +65,24 @@ def test_two_rank_bench_reports_whole_job_throughput():
     pd = out["policy_driven"]
     assert pd["n_gpus"] == 2
     assert abs(pd["value"] - 2 * 4096 * 2 * pd["steps"] / (pd["ms_per_step"] * 1e-3 * pd["steps"])) / pd["value"] < 1e-6
+
+
+def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus 2 ...` as typed (no torch.distributed.run in front): the process turns
+    into the launcher, two fresh ranks run, one JSON line comes back that says how many ranks the
+    collective library saw."""
+    env = dict(os.environ, MARL_AMD_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "8",
+                        "--envs", "4096"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["all_reduce_ranks"] == 2
+    assert out["config"]["process_group"] == "gloo" and out["config"]["rccl_ranks"] is None
+    assert out["config"]["envs_total"] == 2 * 4096
+    assert len(out["roofline"]["us_per_launch_per_rank"]) == 2
+    assert out["roofline"]["us_per_launch"] == pytest.approx(max(out["roofline"]["us_per_launch_per_rank"]), rel=1e-6)
+    assert 0 < out["roofline"]["frac_wall"] <= out["roofline"]["frac"] * 1.001

@@ -69,5 +69,7 @@ def test_bench_runs_through_the_nccl_branch():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["process_group"] == "nccl"
+    # the all-reduce of a device tensor of ones went through RCCL
+    assert out["config"]["world_size"] == 1 and out["config"]["rccl_ranks"] == 1
     # the policy-driven leg takes its maximum over ranks through the same process group
     assert out["policy_driven"]["n_gpus"] == 1 and out["policy_driven"]["value"] > 0
