@@ -131,9 +131,15 @@ class OracleVecEnv:
                                  _p(so), _p(do), _p(obs), self.nthreads)
         return obs
 
-    def step(self, actions, prio_override=None, want_obs=True):
+    def step(self, actions, prio_override=None, want_obs=True, out_obs=None):
+        """`out_obs`: a C-contiguous float32 [E*A, D] array to receive the observations (saves the
+        allocation and first touch of a fresh one at large E)."""
         actions = np.ascontiguousarray(actions, np.int64).reshape(self.E * self.A)
-        obs = np.empty((self.E * self.A, self.D), np.float32) if want_obs else None
+        if out_obs is not None:
+            assert out_obs.dtype == np.float32 and out_obs.shape == (self.E * self.A, self.D) and out_obs.flags.c_contiguous
+            obs = out_obs
+        else:
+            obs = np.empty((self.E * self.A, self.D), np.float32) if want_obs else None
         rew = np.empty(self.E * self.A, np.float32)
         term = np.empty(self.E * self.A, np.uint8)
         trunc = np.empty(self.E * self.A, np.uint8)

@@ -269,6 +269,86 @@ def test_full_size_properties(oracle_mod, layout, A, feature, E):
     assert bool((srt[:, 1:] != srt[:, :-1]).all()), "two agents of an env share a cell"
 
 
+def _host_threads():
+    """every core this job may use (the box exports its share as OMP_NUM_THREADS)"""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(n, share) if share > 0 else n)
+
+
+FULL_SIZE = [
+    ("overcooked_cramped_room_v0", 2, "global_obs", 65536),       # the headline workload
+    ("overcooked_counter_circuit_v0", 2, "global_obs", 131072),   # one GPU's share of the 1M-env job
+    ("overcooked_coordination_ring_v0", 4, "local_obs", 65536),   # four agents, per-agent observations
+]
+
+
+@pytest.mark.parametrize("layout,A,feature,E", FULL_SIZE)
+def test_full_size_every_row_against_oracle(oracle_mod, layout, A, feature, E):
+    """The benchmark sizes with EVERY env followed by the oracle (all host threads): every
+    observation row, reward and flag of every step, the exported state every 10 steps and at
+    each restart, over 60 single steps with episodes of 25 (two in-kernel restarts of every env
+    at full size), then one 32-step launch of marl_env_step_many held to the same bar."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rows = get_layout(layout)
+    N = E * A
+    gpu = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=25, seed=77, env_index_base=3 * E)
+    ora = oracle_mod.OracleVecEnv(rows, A, feature, max_steps=25, num_envs=E, seed=77, env_index_base=3 * E,
+                                  nthreads=_host_threads())
+    D, dev = gpu.D, gpu.device
+    host = torch.empty((N, D), dtype=torch.float32, pin_memory=True)  # the oracle writes here, one upload per step
+    want = torch.empty((N, D), dtype=torch.float32, device=dev)
+
+    def rows_equal(got, what):
+        want.copy_(host, non_blocking=True)
+        if not torch.equal(got, want):
+            bad = torch.nonzero((got != want).any(dim=1)).flatten()[:8].tolist()
+            raise AssertionError(f"{what}: {len(bad)}+ observation rows differ, first {bad}")
+
+    obs_g, _ = gpu.reset()
+    host.numpy()[...] = ora.reset()
+    rows_equal(obs_g[OBS_KEY], "reset")
+    _assert_state_equal(gpu, ora)
+    rng = np.random.default_rng(E + A)
+    restarts = 0
+    for t in range(60):
+        act = _biased_actions(rng, N)
+        o_g, r_g, te_g, tr_g, _ = gpu.step(torch.from_numpy(act))
+        _, r_o, te_o, tr_o = ora.step(act, out_obs=host.numpy())
+        rows_equal(o_g[OBS_KEY], f"step {t}")
+        np.testing.assert_array_equal(r_g.cpu().numpy(), r_o, err_msg=f"rewards differ at step {t}")
+        np.testing.assert_array_equal(te_g.cpu().numpy(), te_o)
+        np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o, err_msg=f"truncated differs at step {t}")
+        if tr_o.any():
+            assert tr_o.all()
+            restarts += 1
+        if t % 10 == 0 or tr_o.any():
+            _assert_state_equal(gpu, ora)
+    assert restarts == 2
+    _assert_state_equal(gpu, ora)
+
+    # one multi-step launch from where the single steps left off: 32 steps, another restart inside
+    K = 32
+    acts = np.stack([_biased_actions(rng, N) for _ in range(K)])
+    obs_k = torch.empty((K, N, D), dtype=torch.float32, device=dev)
+    rew_k = torch.empty((K, N), dtype=torch.float32, device=dev)
+    te_k = torch.empty((K, N), dtype=torch.bool, device=dev)
+    tr_k = torch.empty_like(te_k)
+    gpu.step_many_into(torch.from_numpy(acts).to(dev), obs_k, rew_k, te_k, tr_k)
+    rew_h, te_h, tr_h = rew_k.cpu().numpy(), te_k.cpu().numpy(), tr_k.cpu().numpy()
+    for k in range(K):
+        _, r_o, te_o, tr_o = ora.step(acts[k], out_obs=host.numpy())
+        rows_equal(obs_k[k], f"multi-step launch, step {k}")
+        np.testing.assert_array_equal(rew_h[k], r_o, err_msg=f"multi-step launch: rewards differ at step {k}")
+        np.testing.assert_array_equal(te_h[k], te_o)
+        np.testing.assert_array_equal(tr_h[k], tr_o)
+    assert tr_h.any()
+    _assert_state_equal(gpu, ora)
+
+
 def test_store_policy_does_not_change_rows(monkeypatch):
     """Large observation tensors are stored with a different cache hint; force each policy on the
     same small job (ragged last row group included) and compare every output."""
