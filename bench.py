@@ -134,7 +134,7 @@ def timed(fn, count, dev):
     return ev0.elapsed_time(ev1) * 1e3 / count
 
 
-def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max):
+def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max, shards=1):
     """Policy-driven rollout on every rank (MLP forward + sample + step, the policy reading what the
     step wrote), bracketed like the timed region: barrier + synchronize on both sides, the slowest
     rank's time counts."""
@@ -145,6 +145,13 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
     policy = Agent(env.single_observation_space, env.single_action_space, num_agents=A, num_envs=1,
                    build_centralised=False).to(dev)  # the centralised critic is not evaluated on this path
     policy.use_fused_sampling(1234, row_index_base=rank * N)  # sample + log_prob + entropy in one launch
+    if shards > 1:
+        # the product's pipelined form (as rollout.agent_environment_loop drives a sharded env): every
+        # shard runs forward -> sample -> step on its own stream, no join between steps
+        from marl_amd.sharded_env import ShardedVecEnv
+
+        env = ShardedVecEnv(env.layout_rows, A, env.feature, env.E, shards=shards, max_steps=env.max_steps, seed=1234,
+                            env_index_base=rank * env.E, device=dev)
     env.reset(out=store[0])
 
     # the rollout half of act() as the trainer's rollouts run it (`Agent.rollout_step`): both heads from
@@ -157,13 +164,22 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
         policy.rollout_step(store[i % ring], logp, val, actions_out=act)
         env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
 
+    def shard_step(k, shard, rows, i):
+        policy.rollout_step(store[i % ring][rows], logp[rows], val[rows], actions_out=act[rows], row_offset=rows.start)
+        shard.step_into(act[rows], store[(i + 1) % ring][rows], rew[rows], term[rows], trunc[rows])
+
+    def run(first, count):
+        if shards > 1:
+            env.run_pipelined(range(first, first + count), shard_step)
+        else:
+            for i in range(first, first + count):
+                pstep(i)
+
     steps = 128
-    for i in range(16):
-        pstep(i)
+    run(0, 16)
     barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
-        pstep(16 + i)
+    run(16, steps)
     barrier()
     wall = reduce_max(time.perf_counter() - t0)
     return {
@@ -171,47 +187,39 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
         "value": world * N * steps / wall, "unit": "agent-steps/s", "n_gpus": world, "ms_per_step": wall / steps * 1e3,
         "steps": steps,
         "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs, both heads in one), fused categorical sampling; rows kept; "
-                  "every rank its own envs, no collective, slowest rank's wall time"}
+                  "every rank its own envs, no collective, slowest rank's wall time"
+                  + (f"; the envs of a rank as {shards} shards on streams of their own, each running forward -> sample -> "
+                     "step without a join between steps (ShardedVecEnv.run_pipelined)" if shards > 1 else ""),
+        "shards": shards}
 
 
 def two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E):
-    from marl_amd.env import BatchedOvercookedVecEnv
+    """The product's sharded env (marl_amd.sharded_env.ShardedVecEnv) in its pipelined form: every
+    shard steps on its own stream, replayed from one hipGraph with a branch per shard."""
+    from marl_amd.sharded_env import ShardedVecEnv
 
-    ring, half = store.shape[0], N // 2
-    side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    shards = []
-    for k in range(2):
-        e = BatchedOvercookedVecEnv(env.layout_rows, A, env.feature, E // 2, max_steps=env.max_steps, seed=1234,
-                                    env_index_base=rank * E + k * (E // 2), device=dev)
-        # every shard writes its own half of each tensor of the ring, reads its half of the actions
-        obs = [store[i][k * half:(k + 1) * half] for i in range(ring)]
-        bufs = (torch.empty(half, dtype=torch.float32, device=dev), torch.empty(half, dtype=torch.bool, device=dev),
-                torch.empty(half, dtype=torch.bool, device=dev))
-        acts = actions[:, k * half:(k + 1) * half].contiguous()
-        e.reset(out=obs[0])
-        shards.append((e, obs, bufs, acts))
+    ring = store.shape[0]
+    sh = ShardedVecEnv(env.layout_rows, A, env.feature, E, shards=2, max_steps=env.max_steps, seed=1234,
+                       env_index_base=rank * E, device=dev)
+    rew = torch.empty(N, dtype=torch.float32, device=dev)
+    term = torch.empty(N, dtype=torch.bool, device=dev)
+    trunc = torch.empty(N, dtype=torch.bool, device=dev)
+    sh.reset(out=store[0])
 
-    def chain(k):
-        e, obs, (rew, term, trunc), acts = shards[k]
-        for i in range(ring):
-            e.step_into(acts[i % acts.shape[0]], obs[(i + 1) % ring], rew, term, trunc)
+    def body(k, shard, rows, i):
+        shard.step_into(actions[i % actions.shape[0]][rows], store[(i + 1) % ring][rows], rew[rows], term[rows], trunc[rows])
 
-    chain(0), chain(1)
+    sh.run_pipelined(range(ring), body)
     torch.cuda.synchronize(dev)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        main = torch.cuda.current_stream(dev)
-        for k in range(2):
-            side[k].wait_stream(main)
-            with torch.cuda.stream(side[k]):
-                chain(k)
-        for k in range(2):
-            main.wait_stream(side[k])
+        sh.run_pipelined(range(ring), body)
     g.replay()
     reps = 16
     us = timed(lambda i: g.replay(), reps, dev) / ring
-    return {"regime": f"two shards of {E // 2} envs (env handles of their own) on two streams, single-step launches, one hipGraph "
-                      f"of {ring} steps with a branch per shard and no join between steps; every step's rows kept: HBM",
+    return {"regime": f"marl_amd.sharded_env.ShardedVecEnv, two shards of {E // 2} envs on two streams, single-step launches, "
+                      f"run_pipelined over {ring} steps captured into one hipGraph (a branch per shard, no join between "
+                      "steps); every step's rows kept: HBM",
             "bound": "hbm", "us_per_step": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
             "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
 
@@ -484,12 +492,16 @@ def main():
         dist.all_gather(gathered, mine)
         per_rank_us = [float(g.item()) for g in gathered]
     # north star: random-action AND policy-driven rates at every GPU count
-    policy_line = None
+    policy_line = policy_sharded = None
     if policy is None and not args.no_extra_legs:
         if world == 1:
             holder = {}
             guarded(holder, "policy_driven", lambda: policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max))
             policy_line = holder.get("policy_driven")
+            if E % 2 == 0 and ((N // 2) * D) % 4 == 0:
+                guarded(holder, "policy_driven_two_shards",
+                        lambda: policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max, shards=2))
+                policy_sharded = holder.get("policy_driven_two_shards")
         else:  # several ranks: a rank that fails must end the job, not leave the others at a barrier
             policy_line = policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, reduce_max)
 
@@ -558,6 +570,8 @@ def main():
             out.update(legs)
         if policy_line is not None:
             out["policy_driven"] = policy_line
+        if policy_sharded is not None:
+            out["policy_driven_two_shards"] = policy_sharded
         if world == 1 and not args.no_cpu_baseline:
             guarded(out, "cpu_baseline", lambda: cpu_baseline(rows, A, args.feature, E, 1234))
             guarded(out, "cpu_baseline_1t", lambda: cpu_baseline(rows, A, args.feature, E, 1234, single_thread=True, budget_s=3.0))

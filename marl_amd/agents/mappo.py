@@ -73,16 +73,25 @@ class MAPPO:
                 return self.policy.get_action_and_value(obs, joint_obs=obs.view(1, -1))
             return self.policy.get_action_and_value(obs)
 
-    def act_into(self, obs, step, actions_out):
+    def act_into(self, obs, step, actions_out, rows=None):
         """`act` + the learner-side half of `add_to_buffer` for row `step` of the rollout store:
         log-probabilities and values are written into their rows by the kernels that produce them,
         the int64 actions into `actions_out` (the env reads them there; the driver converts a
         whole rollout of them to the store's float32 at once, `store_actions`).  Call `step` of a
         rollout draws with call number rollout * num_steps + step.  Needs fused sampling; with the
-        centralised critic every row receives the one joint value."""
+        centralised critic every row receives the one joint value.  `rows` (a slice): `obs` and
+        `actions_out` are that slice of the batch's rows (one shard of a pipelined rollout,
+        decentralised critic only); results land in the same slice of the store's rows."""
         buf = self.buffer
-        return self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step], actions_out, slot=step,
-                                        joint=self.centralised)
+        if rows is None:
+            return self.policy.rollout_step(obs, buf.logprobs_buff[step], buf.values_buff[step], actions_out, slot=step,
+                                            joint=self.centralised)
+        return self.policy.rollout_step(obs, buf.logprobs_buff[step][rows], buf.values_buff[step][rows], actions_out,
+                                        slot=step, joint=self.centralised, row_offset=rows.start)
+
+    def can_act_on_shards(self):
+        """per-shard `act_into` calls: fused sampling and a critic that reads only a row's own observation"""
+        return self.can_act_into() and not self.centralised
 
     def begin_direct_rollouts(self, num_steps):
         self.policy.sampler.use_slots(num_steps)

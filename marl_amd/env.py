@@ -111,8 +111,18 @@ def make_env(num_agents=4, layout="large_overcooked_layout", feature="global_obs
     return OvercookedEnvSpec(num_agents, layout, feature, max_steps=max_steps, render_mode=render_mode)
 
 
-def make_vector_env(num_envs, overcooked_env: OvercookedEnvSpec, **kwargs):
-    """main.py:66-96: E copies of the env, agents flattened to rows, one reset issued."""
+def make_vector_env(num_envs, overcooked_env: OvercookedEnvSpec, shards=1, **kwargs):
+    """main.py:66-96: E copies of the env, agents flattened to rows, one reset issued.
+    `shards` > 1: the batch as that many env handles on streams of their own
+    (`sharded_env.ShardedVecEnv`; same envs, same results, rollouts can be pipelined)."""
+    if int(shards) > 1:
+        from .sharded_env import ShardedVecEnv
+
+        vec = ShardedVecEnv(overcooked_env.layout_rows, overcooked_env.config["num_agents"],
+                            overcooked_env.config["features"], num_envs, shards=int(shards),
+                            max_steps=overcooked_env.config["max_steps"], **kwargs)
+        vec.reset()
+        return vec
     vec = BatchedOvercookedVecEnv(
         overcooked_env.layout_rows,
         overcooked_env.config["num_agents"],

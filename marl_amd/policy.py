@@ -261,7 +261,7 @@ class Agent(nn.Module):
             torch.cat([self.actor.weight, self.critic.weight], out=self._head_w)
             torch.cat([self.actor.bias, self.critic.bias], out=self._head_b)
 
-    def rollout_step(self, x, logprob_out, value_out, actions_out=None, slot=None, joint=False):
+    def rollout_step(self, x, logprob_out, value_out, actions_out=None, slot=None, joint=False, row_offset=0):
         """The rollout half of `get_action_and_value` for the decentralised critic, writing the
         log-probabilities and the values straight into the given rows of the rollout store
         (float32 [rows] each) instead of returning fresh tensors that are then copied.  Both
@@ -270,7 +270,11 @@ class Agent(nn.Module):
         `get_action_and_value` to float32 rounding; needs `use_fused_sampling`, no autograd.
         `joint=True`: the value is the centralised critic's, one number for the concatenation of all
         rows (agents/MAPPO.py:70-73, model.py:45), written to every row as the reference's buffer
-        assignment broadcasts it (agent_environment.py:83-84, buffer.py:28)."""
+        assignment broadcasts it (agent_environment.py:83-84, buffer.py:28).
+        `row_offset`: `x` holds rows [row_offset, row_offset + len(x)) of the batch (one shard of a
+        pipelined rollout); they draw the random numbers of those rows.  Not with `joint`."""
+        if joint and row_offset:
+            raise ValueError("the centralised critic reads every row of the batch: no per-shard call")
         if self.sampler is None:
             raise RuntimeError("rollout_step needs use_fused_sampling()")
         if joint:
@@ -285,7 +289,8 @@ class Agent(nn.Module):
         with torch.no_grad():
             heads = torch.addmm(self._head_b, self._trunk(x), self._head_w.t())
             actions, _, _ = self.sampler.sample(heads, want_entropy=False, actions_out=actions_out, logprob_out=logprob_out,
-                                                slot=slot, num_actions=self.actor.out_features, next_column_out=value_out)
+                                                slot=slot, num_actions=self.actor.out_features, next_column_out=value_out,
+                                                row_offset=row_offset)
         return actions
 
     def logits_and_value(self, x):

@@ -127,6 +127,28 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
         trunc_rows = torch.empty((collect_steps, N), dtype=torch.bool, device=device)
         agent.begin_direct_rollouts(collect_steps)
 
+    # An env made of shards on streams of their own (`sharded_env.ShardedVecEnv`) and a learner whose
+    # acting needs nothing beyond a row's own observation: every shard runs act -> step on its own
+    # stream for a whole run of steps, with one fork before and one join after the run.  One shard's
+    # policy GEMMs then overlap the other's env kernel and the drain of its rows; the stored rows
+    # are those of the unsharded run (same env and sampler RNG keys per row).
+    pipelined = direct and getattr(env, "num_shards", 1) > 1 \
+        and bool(getattr(agent, "can_act_on_shards", lambda: False)())
+
+    def shard_step(k, shard, rows, step):
+        agent.act_into(slot(step)[rows], step, act_rows[step][rows], rows=rows)
+        shard.step_into(act_rows[step][rows], slot(step + 1)[rows], buf.rewards_buff[step][rows], term_rows[step][rows],
+                        trunc_rows[step][rows])
+
+    def run_steps(first, count):
+        if pipelined:
+            env.run_pipelined(range(first, first + count), shard_step)
+            buf.ptr = (first + count) % buf.max_size
+            buf.size = min(max(buf.size, first + count), buf.max_size)
+        else:
+            for step in range(first, first + count):
+                one_step(step)
+
     def one_step(step):
         # every tensor touched here has a fixed address per step index, so the same code can be
         # captured into a graph and replayed
@@ -155,8 +177,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
             buf.ptr = first
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                for step in range(first, first + count):
-                    one_step(step)
+                run_steps(first, count)
             if pool is None:
                 pool = g.pool()
             graphs[(first, count)] = g
@@ -165,8 +186,7 @@ def agent_environment_loop(agent, env, device, num_update=1000, log_dir=None, ar
     def run_segment(first, count, warm):
         """steps [first, first + count) of the current rollout"""
         if not (use_graphs and warm):
-            for step in range(first, first + count):
-                one_step(step)
+            run_steps(first, count)
             if direct:
                 stats.add_many(buf.rewards_buff[first:first + count])
             return

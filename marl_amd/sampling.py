@@ -38,13 +38,15 @@ class CategoricalSampler:
         self.counter.add_(self._slots.numel())
 
     def sample(self, logits: torch.Tensor, want_entropy: bool = True, actions_out=None, logprob_out=None, slot=None,
-               num_actions=None, next_column_out=None):
+               num_actions=None, next_column_out=None, row_offset=0):
         """`actions_out` (int64 [rows]) / `logprob_out` (float32 [rows]): contiguous tensors to write
         into, e.g. a row of the rollout store, instead of fresh ones.  `slot`: index of this call
         within its round (see `use_slots`); without it the single counter is used and advanced.
         `num_actions`: the first so many columns of `logits` are the logits (default: all);
         `next_column_out` (float32 [rows]) then receives the column after them, e.g. the critic's
-        value when both heads come out of one GEMM."""
+        value when both heads come out of one GEMM.  `row_offset`: `logits` holds rows
+        [row_offset, row_offset + n) of the batch (a shard of it): they draw the numbers they would
+        draw in a call over the whole batch."""
         if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
             raise ValueError("logits must be a float32 [rows, actions] tensor on the GPU")
         logits = logits.contiguous()
@@ -62,7 +64,8 @@ class CategoricalSampler:
         stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
         counter = self.counter if slot is None else self._slots[slot]
-        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, ld, self.seed, p(counter), self.row_index_base,
+        _lib.check(_lib.lib().marl_sample_categorical(p(logits), n, k, ld, self.seed, p(counter),
+                                                      self.row_index_base + int(row_offset),
                                                       p(actions), p(logprob), p(entropy), p(next_column_out), stream),
                    "marl_sample_categorical")
         if slot is None:

@@ -73,6 +73,10 @@ def build_parser():
                    help="Adam step as one multi-tensor launch (GPU only) or PyTorch's default per-operation launches")
     p.add_argument("--fused-loss", choices=["on", "off"], default="on",
                    help="decentralised MAPPO on the GPU: loss and head gradients from one HIP pass instead of autograd's small ops")
+    p.add_argument("--env-shards", type=int, default=1,
+                   help="run the envs of a rank as this many shards on HIP streams of their own; with the decentralised "
+                        "critic and the fused sampler every shard then runs act -> step on its stream and one shard's "
+                        "policy GEMMs overlap the other's env kernel (same stored rows as with 1)")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
                    help="replay rollout steps from hipGraphs (auto: at most 16,384 rows per launch)")
     return p
@@ -101,7 +105,8 @@ def main(argv=None):
 
     env = make_env(args.num_agents, layout=args.layout, feature=args.feature, render_mode=None,
                    max_steps=args.max_steps)
-    vec_env = make_vector_env(args.num_envs, env, seed=args.seed, env_index_base=rank * args.num_envs, device=device)
+    vec_env = make_vector_env(args.num_envs, env, shards=args.env_shards, seed=args.seed,
+                              env_index_base=rank * args.num_envs, device=device)
     assert vec_env.num_envs == args.num_envs * args.num_agents  # main.py:186
     obs_space, action_space = vec_env.single_observation_space, vec_env.single_action_space
     log_dir = f"logs/run__{int(time.time())}"

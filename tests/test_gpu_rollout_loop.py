@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler, layout="overcooked_cramped_room_v0",
-           feature="global_obs", seed=9, centralised=False):
+           feature="global_obs", seed=9, centralised=False, shards=1):
     from marl_amd.agents import CMAPPO, MAPPO
     from marl_amd.env import make_env, make_vector_env
     from marl_amd.layouts import get_layout
@@ -36,7 +36,7 @@ def _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, fused_sampler
             snaps.append(snap)
             self.buffer.reset()
 
-    vec = make_vector_env(E, env, seed=seed, device=dev)
+    vec = make_vector_env(E, env, shards=shards, seed=seed, device=dev)
     torch.manual_seed(0)
     net = Agent(vec.single_observation_space, vec.single_action_space, A, E).to(dev)
     if fused_sampler:
@@ -158,3 +158,31 @@ def test_reference_shaped_loop_runs_on_the_host_array_env(oracle_mod):
         for k in got:
             np.testing.assert_array_equal(got[k], want[k], err_msg=f"update {u}: {k}")
     assert [x[0] for x in logs].count("reset") == 1 + (T * updates) // (max_steps + 1)
+
+
+@pytest.mark.parametrize("graph_rollout", ["off", "on"])
+@pytest.mark.parametrize("shards,E,A,layout,feature", [
+    (2, 8, 2, "overcooked_cramped_room_v0", "global_obs"),
+    (4, 8, 4, "overcooked_coordination_ring_v0", "local_obs"),
+])
+def test_pipelined_shards_store_what_the_single_handle_driver_stores(oracle_mod, graph_rollout, shards, E, A, layout, feature):
+    """The env as shards on streams of their own, every shard running act -> step for a whole run of
+    steps without a join in between: held to the restated reference loop like the single-handle
+    driver, and to the single-handle driver itself (same actions drawn, same rows stored)."""
+    T, updates, max_steps = 16, 5, 10
+    snaps, ref, returns, freq, ref_returns, ref_freq, net, _ = _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout,
+                                                                     True, layout=layout, feature=feature, shards=shards)
+    for u, (got, want) in enumerate(zip(snaps, ref)):
+        for k in ("obs", "actions", "rewards", "dones", "next_obs"):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=f"update {u}: {k}")
+    assert returns == ref_returns and len(returns) == (T * updates) // (max_steps + 1)
+    for k in ("frequency_delivery_per_episode", "frequency_plated_per_episode", "frequency_ingredient_in_pot_per_episode"):
+        assert [float(x) for x in freq[k]] == [float(x) for x in ref_freq[k]], k
+    one, *_ = _drive(oracle_mod, E, A, T, updates, max_steps, graph_rollout, True, layout=layout, feature=feature, shards=1)
+    for u, (got, want) in enumerate(zip(snaps, one)):
+        # a shard's GEMMs have fewer rows than the whole batch's and may sum in another order: the
+        # policy outputs agree to float32 rounding, and the actions drawn from them here exactly
+        for k in ("actions", "obs", "rewards", "dones", "next_obs"):
+            assert torch.equal(got[k], want[k]), f"update {u}: {k} differs from the single-handle driver"
+        torch.testing.assert_close(got["logprobs"], want["logprobs"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(got["values"], want["values"], rtol=1e-4, atol=1e-5)
