@@ -42,7 +42,6 @@ int reward_event_chunks(int N);
 hipError_t launch_sample_categorical(const float* logits, int N, int K, int ld, uint32_t key, const uint64_t* counter,
                                      uint64_t row_base, long long* actions, float* logprob, float* entropy,
                                      float* next_col, hipStream_t stream);
-hipError_t launch_expand(const void* img, float* out, size_t count, int policy, hipStream_t stream);
 int ppo_loss_chunks(int M);
 hipError_t launch_ppo_loss(const float* logits, int M, int K, int ld, const float* values, const long long* index,
                            const float* actions_f, const float* old_logprob, const float* advantages,
@@ -74,24 +73,11 @@ struct marl_env {
     EnvParams P;
     int A, feat, niw, H, W, ncell, NP, D, BLK, words;
     int device;                // HIP device that holds the tables; every call must run with it current
+    int stream_nt_forced;      // MARL_AMD_STREAM_NT as read when the handle was made: 0 / 1, -1 = not set
     std::vector<uint8_t> tab;  // host copy of the hot lookup blob
     std::vector<uint8_t> aux;  // host copy of the cell-indexed tables of the snapshot kernels
     uint8_t* d_tab;
     uint8_t* d_aux;
-#ifdef OC_SPLIT
-    // (diagnostic build, profiles/diag/build_variants.sh split:-DOC_SPLIT; measured slower than the
-    // fused multi-step launch, see profiles/r02/split_form.txt)
-    // split form of the multi-step call (rows larger than the last-level cache): the simulation
-    // kernel leaves int8 rows in a small ring, a second stream widens them to float32
-    static constexpr int MAX_RING = 8;
-    int split_ring;            // ring slots, 0 = split form not set up
-    int split_policy;          // store policy of the widening kernel
-    int split_mode;            // diagnostic: 0 two streams, 1 one stream, 2 simulation only, 3 widening only
-    uint8_t* d_ring;           // int8 [split_ring][E * A * D], each slot 256-byte aligned
-    size_t ring_slot_bytes;
-    hipStream_t split_stream;
-    hipEvent_t ev_sim[MAX_RING], ev_exp[MAX_RING];
-#endif
 };
 
 // ---------------------------------------------------------------------------------------
@@ -385,13 +371,6 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, int W, con
 // 159 MB it gains 1 %, from 212 MB on 3-5 %: the crossover is where the rows stop fitting the
 // 256 MiB last-level cache together with everything else the step touches.
 static constexpr size_t STREAM_NT_THRESHOLD_BYTES = (size_t)128 << 20;
-#ifdef OC_SPLIT
-// Observation bytes per step from which marl_env_step_many runs in its split form (rows that a
-// multi-step call writes are kept, so they drain to HBM whatever one step's size; the split form
-// pays once a step's launch is long enough to hide its two kernels behind each other).
-static constexpr size_t SPLIT_THRESHOLD_BYTES = (size_t)64 << 20;
-static constexpr int SPLIT_DEFAULT_RING = 3;
-#endif
 
 extern "C" const char* marl_last_error(void) { return g_err.c_str(); }
 
@@ -409,18 +388,16 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
     if (dist_metric != 0 && dist_metric != 1) return fail(MARL_ERR_INVALID, "dist_metric must be 0 or 1");
     marl_env* env = new marl_env();
     env->A = num_agents; env->feat = feature; env->d_tab = nullptr; env->d_aux = nullptr;
-#ifdef OC_SPLIT
-    env->split_ring = 0; env->d_ring = nullptr; env->split_stream = nullptr; env->split_policy = 0;
-#endif
     int rc = build_tables(env, layout_rows, height, dist_metric);
     if (rc != MARL_OK) { delete env; return rc; }
     EnvParams& P = env->P;
-    P.E = num_envs; P.max_steps = max_steps; P.auto_reset = 1; P.nsteps = 1; P.img_out = 0;
+    P.E = num_envs; P.max_steps = max_steps; P.auto_reset = 1; P.nsteps = 1;
     {
         // MARL_AMD_STREAM_NT=0/1 forces the choice (tuning aid)
         const size_t obs_bytes = (size_t)num_envs * num_agents * env->D * sizeof(float);
         const char* v = getenv("MARL_AMD_STREAM_NT");
-        P.stream_nt = v ? (atoi(v) != 0) : (obs_bytes > STREAM_NT_THRESHOLD_BYTES);
+        env->stream_nt_forced = v ? (atoi(v) != 0) : -1;
+        P.stream_nt = v ? env->stream_nt_forced : (obs_bytes > STREAM_NT_THRESHOLD_BYTES);
     }
     uint32_t k = mix32_host((uint32_t)seed + 0x9E3779B9u);
     P.seed_key = mix32_host(k ^ (uint32_t)(seed >> 32));
@@ -437,44 +414,6 @@ extern "C" int marl_env_create(marl_env_t** out, const char* const* layout_rows,
         delete env;
         return fail_hip(e, "device allocation / upload of the lookup tables");
     }
-#ifdef OC_SPLIT
-    {
-        // MARL_AMD_SPLIT=<ring slots> forces the split form of marl_env_step_many (0 = never);
-        // by default it is used when one step's rows would not stay in the last-level cache
-        const size_t obs_bytes = (size_t)num_envs * num_agents * env->D * sizeof(float);
-        const char* v = getenv("MARL_AMD_SPLIT");
-        int ring = v ? atoi(v) : 0;  // off unless asked for
-        (void)obs_bytes;
-        if (ring < 0) ring = 0;
-        if (ring == 1) ring = 2;
-        if (ring > marl_env::MAX_RING) ring = marl_env::MAX_RING;
-        const char* pv = getenv("MARL_AMD_SPLIT_POLICY");
-        env->split_policy = pv ? atoi(pv) : 0;
-        const char* mv = getenv("MARL_AMD_SPLIT_MODE");
-        env->split_mode = mv ? atoi(mv) : 0;
-        if (ring > 0) {
-            env->ring_slot_bytes = (((size_t)num_envs * num_agents * env->D) + 255) & ~(size_t)255;
-            e = hipMalloc(reinterpret_cast<void**>(&env->d_ring), env->ring_slot_bytes * ring);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&env->split_stream, hipStreamNonBlocking);
-            int made = 0;
-            for (; e == hipSuccess && made < ring; ++made) {
-                e = hipEventCreateWithFlags(&env->ev_sim[made], hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&env->ev_exp[made], hipEventDisableTiming);
-                else break;
-                if (e != hipSuccess) { (void)hipEventDestroy(env->ev_sim[made]); break; }
-            }
-            if (e != hipSuccess) {
-                for (int k = 0; k < made; ++k) { (void)hipEventDestroy(env->ev_sim[k]); (void)hipEventDestroy(env->ev_exp[k]); }
-                if (env->split_stream) (void)hipStreamDestroy(env->split_stream);
-                if (env->d_ring) (void)hipFree(env->d_ring);
-                (void)hipFree(env->d_tab); (void)hipFree(env->d_aux);
-                delete env;
-                return fail_hip(e, "setting up the split form (ring, stream, events)");
-            }
-            env->split_ring = ring;
-        }
-    }
-#endif
     *out = env;
     return MARL_OK;
 }
@@ -483,14 +422,6 @@ extern "C" void marl_env_destroy(marl_env_t* env) {
     if (!env) return;
     if (env->d_tab) (void)hipFree(env->d_tab);
     if (env->d_aux) (void)hipFree(env->d_aux);
-#ifdef OC_SPLIT
-    if (env->split_ring > 0) {
-        (void)hipStreamSynchronize(env->split_stream);
-        for (int k = 0; k < env->split_ring; ++k) { (void)hipEventDestroy(env->ev_sim[k]); (void)hipEventDestroy(env->ev_exp[k]); }
-        (void)hipStreamDestroy(env->split_stream);
-        (void)hipFree(env->d_ring);
-    }
-#endif
     delete env;
 }
 
@@ -522,7 +453,7 @@ static int check_device(const marl_env* env) {
 
 static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, int act_size, const uint8_t* prio,
                           const uint8_t* spawn_ov, const uint8_t* dir_ov, float* d_obs, float* d_rewards,
-                          uint8_t* d_term, uint8_t* d_trunc, int mode, void* stream, int nsteps = 1, int img_out = 0) {
+                          uint8_t* d_term, uint8_t* d_trunc, int mode, void* stream, int nsteps = 1) {
     if (!env) return fail(MARL_ERR_INVALID, "env is NULL");
     if (!d_state) return fail(MARL_ERR_INVALID, "d_state is NULL");
     if (!d_obs) return fail(MARL_ERR_INVALID, "d_obs is NULL");
@@ -534,12 +465,10 @@ static int run_env_kernel(marl_env* env, void* d_state, const void* d_actions, i
     uint32_t* st = reinterpret_cast<uint32_t*>(d_state);
     EnvParams P = env->P;
     P.nsteps = nsteps;
-    P.img_out = img_out;
-    if (nsteps > 1) {
+    if (nsteps > 1 && env->stream_nt_forced < 0) {
         // the cache policy follows what the launch writes: all steps' rows
-        const char* v = getenv("MARL_AMD_STREAM_NT");
         const size_t obs_bytes = (size_t)nsteps * (size_t)P.E * env->A * env->D * sizeof(float);
-        P.stream_nt = v ? (atoi(v) != 0) : (obs_bytes > STREAM_NT_THRESHOLD_BYTES);
+        P.stream_nt = obs_bytes > STREAM_NT_THRESHOLD_BYTES;
     }
     switch (env->A) {
         case 1: e = launch_env_kernel_A<1>(env->feat, env->niw, P, env->d_tab, env->d_aux, st, d_actions, act_size, prio, spawn_ov, dir_ov, d_obs, d_rewards, d_term, d_trunc, mode, s); break;
@@ -580,54 +509,6 @@ extern "C" int marl_env_step(marl_env_t* env, void* d_state, const void* d_actio
                           d_rewards, d_terminated, d_truncated, ablate << 8, stream);
 }
 
-#ifdef OC_SPLIT
-// The multi-step call as a two-stage pipeline.  Step k's simulation (on the caller's stream) leaves
-// its rows as int8 in ring slot k % R; the widening kernel of step k (on the env's second stream)
-// waits for it and writes the float32 rows; the simulation of step k + R waits until that slot has
-// been read.  The caller's stream finally waits for the last widening kernel, so the call keeps
-// stream semantics: whatever is queued behind it sees all rows.  Same results as single steps.
-static int step_many_split(marl_env* env, void* d_state, const void* d_actions, int act_size, int num_steps,
-                           float* d_obs, float* d_rewards, uint8_t* d_term, uint8_t* d_trunc, const uint8_t* prio,
-                           void* stream) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int R = env->split_ring;
-    const size_t N = (size_t)env->P.E * env->A, ND = N * (size_t)env->D;
-    hipError_t e;
-    if (env->split_mode != 0) {
-        for (int k = 0; k < num_steps; ++k) {
-            uint8_t* img = env->d_ring + (size_t)(k % R) * env->ring_slot_bytes;
-            if (env->split_mode != 3) {
-                const int rc = run_env_kernel(env, d_state, reinterpret_cast<const char*>(d_actions) + (size_t)k * N * act_size,
-                                              act_size, prio ? prio + (size_t)k * N : nullptr, nullptr, nullptr,
-                                              reinterpret_cast<float*>(img), d_rewards + (size_t)k * N, d_term + (size_t)k * N,
-                                              d_trunc + (size_t)k * N, 0, stream, 1, 1);
-                if (rc != MARL_OK) return rc;
-            }
-            if (env->split_mode != 2 &&
-                (e = launch_expand(img, d_obs + (size_t)k * ND, ND, env->split_policy, s)) != hipSuccess)
-                return fail_hip(e, "expand kernel launch");
-        }
-        return MARL_OK;
-    }
-    for (int k = 0; k < num_steps; ++k) {
-        const int slot = k % R;
-        uint8_t* img = env->d_ring + (size_t)slot * env->ring_slot_bytes;
-        if (k >= R && (e = hipStreamWaitEvent(s, env->ev_exp[slot], 0)) != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
-        const int rc = run_env_kernel(env, d_state, reinterpret_cast<const char*>(d_actions) + (size_t)k * N * act_size,
-                                      act_size, prio ? prio + (size_t)k * N : nullptr, nullptr, nullptr,
-                                      reinterpret_cast<float*>(img), d_rewards + (size_t)k * N, d_term + (size_t)k * N,
-                                      d_trunc + (size_t)k * N, 0, stream, 1, 1);
-        if (rc != MARL_OK) return rc;
-        if ((e = hipEventRecord(env->ev_sim[slot], s)) != hipSuccess) return fail_hip(e, "hipEventRecord");
-        if ((e = hipStreamWaitEvent(env->split_stream, env->ev_sim[slot], 0)) != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
-        if ((e = launch_expand(img, d_obs + (size_t)k * ND, ND, env->split_policy, env->split_stream)) != hipSuccess)
-            return fail_hip(e, "expand kernel launch");
-        if ((e = hipEventRecord(env->ev_exp[slot], env->split_stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
-    }
-    if ((e = hipStreamWaitEvent(s, env->ev_exp[(num_steps - 1) % R], 0)) != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
-    return MARL_OK;
-}
-#endif
 
 extern "C" int marl_env_step_many(marl_env_t* env, void* d_state, const void* d_actions, int action_elem_size,
                                   int num_steps, float* d_obs, float* d_rewards, uint8_t* d_terminated,
@@ -643,11 +524,6 @@ extern "C" int marl_env_step_many(marl_env_t* env, void* d_state, const void* d_
     if (env && (((size_t)env->P.E * env->A * env->D) & 3u) != 0 && num_steps > 1)
         return fail(MARL_ERR_INVALID, "rows of one step must be a multiple of 16 bytes for a multi-step launch "
                                       "(every step's rows start 16-byte aligned)");
-#ifdef OC_SPLIT
-    if (env && env->split_ring > 0 && num_steps > 1)
-        return step_many_split(env, d_state, d_actions, action_elem_size, num_steps, d_obs, d_rewards, d_terminated,
-                               d_truncated, d_prio_override, stream);
-#endif
     return run_env_kernel(env, d_state, d_actions, action_elem_size, d_prio_override, nullptr, nullptr, d_obs,
                           d_rewards, d_terminated, d_truncated, 0, stream, num_steps);
 }

@@ -37,6 +37,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -863,7 +864,6 @@ __device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, cons
 // ---------------------------------------------------------------------------------------
 #define OC_KERNEL_NAME env_kernel
 #define OC_MANY 0
-#define OC_IMG 0
 #include "env_kernel_body.inc"
 #undef OC_KERNEL_NAME
 #undef OC_MANY
@@ -872,16 +872,6 @@ __device__ __forceinline__ void write_row_pair(uint8_t* img, uint32_t lane, cons
 #include "env_kernel_body.inc"
 #undef OC_KERNEL_NAME
 #undef OC_MANY
-#undef OC_IMG
-#ifdef OC_SPLIT  // diagnostic build only: the split form measured slower (profiles/r02/split_form.txt)
-#define OC_KERNEL_NAME env_kernel_img
-#define OC_MANY 0
-#define OC_IMG 1
-#include "env_kernel_body.inc"
-#undef OC_KERNEL_NAME
-#undef OC_MANY
-#undef OC_IMG
-#endif
 
 // ---------------------------------------------------------------------------------------
 // dispatch
@@ -892,12 +882,16 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
                              float* obs, float* rewards, uint8_t* term, uint8_t* trunc, int mode,
                              hipStream_t stream) {
     using G = FeatGeom<A, FEAT>;
-    // 4 waves per workgroup unless their row images would not fit 64 KiB of LDS
+    // 4 waves per workgroup (the kernel is bounded to 256 threads; the lookup blob is staged once per
+    // workgroup) unless their row images would not fit 64 KiB of LDS: a CU's 160 KiB then hold two
+    // such workgroups, and narrower ones of the wide-row cases fill it equally well.
     static const int waves_req = [] { const char* v = getenv("MARL_AMD_WAVES"); return v ? atoi(v) : 4; }();  // tuning aid
-    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4) ? waves_req : 4;  // the kernel is bounded to 256 threads
+    int waves = (waves_req == 1 || waves_req == 2 || waves_req == 4) ? waves_req : 4;
     constexpr int RPW = 64 / lanes_per_env(A) * A;  // rows per wave
-    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * RPW * G::D > 64 * 1024) waves >>= 1;
-    const size_t lds = (size_t)P.tab_bytes + (size_t)waves * RPW * G::D;
+    constexpr int IMG = RPW * G::D;                 // bytes of a wave's row image
+    static const size_t wg_cap = [] { const char* v = getenv("MARL_AMD_LDS_CAP_KB"); return (size_t)(v ? atoi(v) : 64) * 1024; }();  // tuning aid
+    while (waves > 1 && (size_t)P.tab_bytes + (size_t)waves * IMG > wg_cap) waves >>= 1;
+    const size_t lds = (size_t)P.tab_bytes + (size_t)waves * IMG;
     // dynamic-LDS limit already granted to this instantiation's kernels, per device; host threads
     // that step different handles of one family at the same time meet here
     static size_t configured[64] = {0};
@@ -911,11 +905,6 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
         if (err == hipSuccess)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel_many<A, FEAT, NIW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#ifdef OC_SPLIT
-        if (err == hipSuccess)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel_img<A, FEAT, NIW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#endif
         if (err != hipSuccess) return err;
         configured[dev] = lds;
     }
@@ -923,13 +912,6 @@ static hipError_t launch_one(const EnvParams& P, const uint8_t* tab, const uint8
     const size_t N = (size_t)P.E * A;
     const size_t rows_per_block = (size_t)waves * RPW;
     const unsigned grid = (unsigned)((N + rows_per_block - 1) / rows_per_block);
-#ifdef OC_SPLIT
-    if (P.img_out) {
-        hipLaunchKernelGGL((env_kernel_img<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
-                           actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);
-        return hipGetLastError();
-    }
-#endif
     if (P.nsteps > 1 && (mode & 0xFF) == 0)
         hipLaunchKernelGGL((env_kernel_many<A, FEAT, NIW>), dim3(grid), dim3(waves * 64), lds, stream, P, tab, aux, state,
                            actions, act_size, prio, spawn_ov, dir_ov, obs, rewards, term, trunc, mode);

@@ -127,7 +127,6 @@ struct EnvParams {
     int auto_reset;   // 1: a truncated env restarts inside the step (vector-env semantics)
     int stream_nt;    // 1: observation rows exceed the last-level cache, store them non-temporally
     int nsteps;       // consecutive steps worked off by one launch (1 for the plain step entry point)
-    int img_out;      // 1: rows are left as int8 in an int8 tensor of the observation's shape (split form)
     int off_nb, off_postab, off_adj, off_frc, off_slotrc, off_potorder, off_spawnf, off_inttab, off_rewtab, off_rewval;
     uint32_t seed_key;                  // mix of the 64-bit seed
     uint32_t env_base_lo, env_base_hi;  // global index of env 0 of this shard

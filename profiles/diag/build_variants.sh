@@ -11,7 +11,6 @@ build() {  # name flags...
   /opt/rocm/bin/hipcc $F -c marl_amd/csrc/stats_kernels.hip -o $d/stats.o &
   /opt/rocm/bin/hipcc $F -c marl_amd/csrc/sample_kernels.hip -o $d/sample.o &
   /opt/rocm/bin/hipcc $F -c marl_amd/csrc/ppo_kernels.hip -o $d/ppo.o &
-  /opt/rocm/bin/hipcc $F -c profiles/diag/expand_kernels.hip -o $d/expand.o &
   /opt/rocm/bin/hipcc $F -c marl_amd/csrc/capi.hip -o $d/capi.o &
   wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o profiles/diag/libvar_$name.so $d/*.o
