@@ -71,8 +71,9 @@ void marl_env_destroy(marl_env_t *env);
 /*
  * The reference steps cogrid through a vector wrapper that restarts a finished env inside
  * step() (default here, enabled = 1).  A bare cogrid env (tests/test_load.py:104-111) does not:
- * with enabled = 0 a truncated env keeps its final state and observation, t keeps counting,
- * and the caller resets.
+ * with enabled = 0 a truncated env keeps its final state and observation, t keeps counting (a
+ * 32-bit counter: `truncated` stays set however long the caller goes on stepping), and the
+ * caller resets.
  */
 int marl_env_set_auto_reset(marl_env_t *env, int enabled);
 
@@ -129,9 +130,11 @@ int marl_env_featurize(marl_env_t *env, void *d_state, float *d_obs, void *strea
  *   d_pots   int32 [E][NP][2] = (onion count, cooking timer)
  *   d_items  uint8 [E][H*W]  item lying on each floor / counter cell
  *   d_misc   int32 [E][2]    = (t, RNG draw counter)
- * Import does not judge the snapshot: codes are masked to their field widths and an agent placed
- * off the grid or off the floor goes to the first floor cell.  Callers validate beforehand (the
- * Python host does: marl_amd/env.py, _validate_snapshot).
+ * Import does not judge the snapshot, but whatever the arrays hold it stays inside the library's
+ * tables: codes are masked to their field widths and an agent placed off the grid (each coordinate
+ * is tested against its own bound) or off the floor goes to the first floor cell.  A snapshot that
+ * is to mean something is validated by the caller beforehand (the Python host does:
+ * marl_amd/env.py, _validate_snapshot).
  */
 int marl_env_export_state(marl_env_t *env, const void *d_state, int32_t *d_agents, int32_t *d_pots,
                           uint8_t *d_items, int32_t *d_misc, void *stream);
@@ -182,7 +185,10 @@ size_t marl_reward_events_workspace_bytes(int num_envs, int num_agents);
  * (e.g. the rows a rollout has just stored, agent_environment.py:63-76 applied to each in turn).
  * Results equal num_steps marl_reward_events calls in step order, bit for bit (the rows-0..1 return is
  * accumulated step after step).  d_workspace: marl_reward_events_many_workspace_bytes() bytes, 8-byte aligned.
+ * At most MARL_REWARD_EVENTS_MANY_MAX_STEPS steps per call (a rollout's worth; the finishing pass is one
+ * workgroup that walks the steps in order); longer runs are passed in pieces.
  */
+#define MARL_REWARD_EVENTS_MANY_MAX_STEPS 4096
 int marl_reward_events_many(const float *d_rewards, int num_steps, int num_envs, int num_agents,
                             uint64_t *d_totals, double *d_first_rows, void *d_workspace, void *stream);
 size_t marl_reward_events_many_workspace_bytes(int num_steps, int num_envs, int num_agents);

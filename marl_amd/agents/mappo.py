@@ -134,9 +134,11 @@ class MAPPO:
             logits, newvalue = self.policy.logits_and_value(b_obs[mb])
             if self.fused_target == "minibatch_mean":
                 # agents/CentralizedMAPPO.py:36-46: every sample regresses onto the mean target of its minibatch
+                # (the mean of THIS rank's minibatch, as in the reference's one process; the pass reads
+                # the target of a sample at the sample's index, so only those entries are written)
                 if self._mean_target is None or self._mean_target.shape != b_value_target.shape:
                     self._mean_target = torch.empty_like(b_value_target)
-                self._mean_target.copy_(b_value_target[mb].mean().expand_as(self._mean_target))
+                self._mean_target.index_copy_(0, mb, b_value_target[mb].mean().expand(mb.numel()))
                 b_value_target = self._mean_target
             loss, stats = ppo_loss(logits, newvalue, mb, b_actions_f, b_logprobs, b_advantages, b_value_target,
                                    self.clip_param, self.entropy_coef, self.value_loss_coef)

@@ -299,7 +299,7 @@ __global__ void export_kernel(EnvParams P, int A, int niw, int ncell, int W, con
     if (e >= P.E) return;
     const size_t E = (size_t)P.E;
     int w = 0;
-    misc[2 * e] = (int32_t)(st[(w++) * E + e] & 0xFFFFu);
+    misc[2 * e] = (int32_t)st[(w++) * E + e];
     misc[2 * e + 1] = (int32_t)st[(w++) * E + e];
     const uint32_t pw = st[(w++) * E + e];
     for (int p = 0; p < P.NP; ++p) {
@@ -330,7 +330,7 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, int W, con
     if (e >= P.E) return;
     const size_t E = (size_t)P.E;
     int w = 0;
-    st[(w++) * E + e] = (uint32_t)misc[2 * e] & 0xFFFFu;
+    st[(w++) * E + e] = (uint32_t)misc[2 * e];
     st[(w++) * E + e] = (uint32_t)misc[2 * e + 1];
     uint32_t pw = 0;
     for (int p = 0; p < P.NP; ++p) {
@@ -345,7 +345,8 @@ __global__ void import_kernel(EnvParams P, int A, int niw, int ncell, int W, con
             const int32_t* o = agents + ((size_t)e * A + 2 * k + h) * 4;
             // a position off the grid or off the floor is replaced by the first floor cell: the
             // lookup must stay inside the table whatever the caller uploaded
-            const bool inside = o[0] >= 0 && o[1] >= 0 && o[1] < W && o[0] * W + o[1] < ncell;
+            // (each coordinate against its own bound: a product of hostile values could wrap into range)
+            const bool inside = o[0] >= 0 && o[0] < ncell / W && o[1] >= 0 && o[1] < W;
             uint32_t fi = inside ? aux[AUX_FIDX_OF_CELL + (uint32_t)(o[0] * W + o[1])] : 0xFFu;
             fi = fi == 0xFFu ? 0u : fi;
             const uint32_t v = fi | (((uint32_t)o[2] & 3u) << 8) | (((uint32_t)o[3] & 3u) << 10);
@@ -624,7 +625,9 @@ extern "C" size_t marl_reward_events_many_workspace_bytes(int num_steps, int num
 extern "C" int marl_reward_events_many(const float* d_rewards, int num_steps, int num_envs, int num_agents,
                                        uint64_t* d_totals, double* d_first_rows, void* d_workspace, void* stream) {
     if (!d_rewards || !d_totals || !d_workspace) return fail(MARL_ERR_INVALID, "NULL argument to marl_reward_events_many");
-    if (num_steps <= 0 || num_steps > 65535) return fail(MARL_ERR_INVALID, "num_steps must be in [1, 65535]");
+    // (the finishing pass is one workgroup that walks the steps in order: kept to rollout lengths)
+    if (num_steps <= 0 || num_steps > MARL_REWARD_EVENTS_MANY_MAX_STEPS)
+        return fail(MARL_ERR_INVALID, "num_steps must be in [1, " + std::to_string(MARL_REWARD_EVENTS_MANY_MAX_STEPS) + "]");
     if (num_envs <= 0 || num_agents <= 0 || (int64_t)num_envs * num_agents > 0x7FFFFFFF)
         return fail(MARL_ERR_INVALID, "num_envs and num_agents must be positive and their product below 2^31");
     if (((uintptr_t)d_workspace & 7u) != 0 || ((uintptr_t)d_totals & 7u) != 0 || ((uintptr_t)d_first_rows & 7u) != 0)

@@ -202,7 +202,7 @@ __device__ __forceinline__ void load_raw(uint32_t (&raw)[3 + (A + 1) / 2 + NIW],
 
 template <int A, int NIW>
 __device__ __forceinline__ void unpack_state(EnvState<A, NIW>& s, const uint32_t (&raw)[3 + (A + 1) / 2 + NIW]) {
-    s.t = raw[0] & 0xFFFFu;
+    s.t = raw[0];  // the whole word: without auto-reset the counter runs on past max_steps
     s.rng.ctr = raw[1];
     s.pots = raw[2];
     static_for<0, (A + 1) / 2>([&](auto K) {

@@ -140,7 +140,7 @@ constexpr int AUX_CELL_OF_SLOT = 768;  // u8[256] item slot -> cell
 constexpr int AUX_BYTES = 1024;
 
 // per-env packed state, struct-of-arrays: word w of env e lives at state[w * E + e]
-//   word 0: t (bits 0-15)
+//   word 0: t, steps since the episode began (all 32 bits; at most max_steps <= 65535 while envs auto-reset)
 //   word 1: RNG draw counter
 //   word 2: pots, one byte each: count (bits 0-1) | timer (bits 2-6)
 //   then (A+1)/2 agent words, 16 bits per agent: floor index (0-7) | dir (8-9) | inv (10-11)

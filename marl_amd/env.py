@@ -364,8 +364,8 @@ class BatchedOvercookedVecEnv:
             raise ValueError("snapshot has an item under an agent")
         if self.NP and ((pots[..., 0] < 0) | (pots[..., 0] > 3) | (pots[..., 1] < 0) | (pots[..., 1] > 30)).any():
             raise ValueError("snapshot has an out-of-range pot")
-        if ((misc[:, 0] < 0) | (misc[:, 0] > 65535)).any():
-            raise ValueError("snapshot has an out-of-range step counter")
+        if (misc[:, 0] < 0).any():
+            raise ValueError("snapshot has a negative step counter")
 
     # ------------------------------------------------------------------
     def close(self):

@@ -16,6 +16,8 @@ from . import _lib
 
 
 class EpisodeStats:
+    MAX_STEPS_PER_CALL = 4096  # MARL_REWARD_EVENTS_MANY_MAX_STEPS of include/marl_amd.h
+
     def __init__(self, num_envs: int, num_agents: int, device):
         self.E, self.A = int(num_envs), int(num_agents)
         self.device = torch.device(device)
@@ -50,6 +52,10 @@ class EpisodeStats:
         if rewards.shape[1] != self.E * self.A:
             raise ValueError(f"rewards has {rewards.shape[1]} entries per step, expected {self.E * self.A}")
         if K == 0:
+            return
+        if K > self.MAX_STEPS_PER_CALL:  # the library takes a rollout's worth of steps per call
+            for first in range(0, K, self.MAX_STEPS_PER_CALL):
+                self.add_many(rewards[first:first + self.MAX_STEPS_PER_CALL])
             return
         L = _lib.lib()
         need = max(int(L.marl_reward_events_many_workspace_bytes(K, self.E, self.A)), 8) // 8

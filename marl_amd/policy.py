@@ -3,12 +3,13 @@
 ReLU), ``actor`` (256 -> n_actions), ``critic`` (256 -> 1) and ``centralised_critics.{0,2,4}``
 (obs_dim * num_agents * num_envs -> 512 -> 256 -> 1).  All layers start orthogonal with gain
 sqrt(2) and zero bias (model.py:6-9).  The matrix products run on PyTorch-ROCm (rocBLAS /
-hipBLASLt); nothing here is hand-written HIP; which library call computes a layer is chosen
-per shape for small batches (`_small_gemm_form`)."""
+hipBLASLt); nothing here is hand-written HIP; which library call computes a layer of a small
+batch is a fixed function of its shape (`_table_form`)."""
 from __future__ import annotations
 
 import math
 import os
+import threading
 import warnings
 
 import torch
@@ -39,16 +40,30 @@ def _weight_grad(gy, x):
 # Below 512 rows (the reference's batch sizes: 16 envs x 2 agents = 32 rows per rollout step)
 # hipBLASLt's pick for the fused call is erratic on MI355X: rows x 512 -> 256 takes 17.8 us at 32
 # rows, 60 us at 128, 118 us at 256 and 6 us at 512, while a plain rocBLAS product takes 3.7 us at
-# all of them (plus two small in-place launches for bias and ReLU); for other layers of the same
-# MLP the fused call wins (rows x 202 -> 512: 5.4 against 7.5 us).  No rule in the shape predicts
-# it, so each (rows, in, out) shape below 512 rows is timed once (both forms replayed from a
-# hipGraph, outside any capture in progress) and the decision kept; MARL_AMD_SMALL_GEMM=fused|plain forces one form.  (profiles/diag/small_gemm2.py)
+# all of them (plus two small in-place launches for bias and ReLU); for the other layers of the same
+# MLP the fused call wins (rows x 202 -> 512: 5.4 against 7.5 us).  (profiles/diag/small_gemm2.py)
+# The forms sum in different orders, so which one runs must not depend on anything that varies from
+# run to run or from rank to rank: it is a fixed function of the layer's shape (`_TABLE_FORM`).
+# MARL_AMD_SMALL_GEMM=fused|plain|gemv forces one form; MARL_AMD_SMALL_GEMM=tune times the forms once
+# per shape instead (a tuning aid: its choices can differ between runs, and with them the bits of a
+# seeded run).
 _SMALL_ROWS = 512
 _GEMM_CHOICE = {}
+_BLAS_LOCK = threading.Lock()
+
+
+def _table_form(rows, in_features, out_features):
+    """the measured winners on MI355X: a single row (the centralised critic's joint observation) as a
+    matrix-vector product; the 512-wide hidden layer through rocBLAS; everything else fused"""
+    if rows == 1 and in_features >= 1024:
+        return "gemv"
+    if in_features == 512 and out_features <= 256:
+        return "plain"
+    return "fused"
 
 
 def gemm_choices():
-    """the decisions taken so far, {(rows, in_features, out_features, relu): "fused" | "plain"}"""
+    """the forms in use so far, {(rows, in_features, out_features, relu): "fused" | "plain" | "gemv"}"""
     return dict(_GEMM_CHOICE)
 
 
@@ -86,12 +101,13 @@ def _announce_blas_switch_quietly(t):
 def _plain_linear(x, weight, bias, relu):
     """the product through rocBLAS, bias and ReLU as in-place launches of their own"""
     blas = torch.backends.cuda.preferred_blas_library
-    prev = blas()
-    blas("hipblas")
-    try:
-        out = torch.mm(x, weight.t())
-    finally:
-        blas(prev)
+    with _BLAS_LOCK:  # the preference is process-wide: one thread at a time, always put back
+        prev = blas()
+        blas("hipblas")
+        try:
+            out = torch.mm(x, weight.t())
+        finally:
+            blas(prev)
     out.add_(bias)
     return out.relu_() if relu else out
 
@@ -113,9 +129,11 @@ def _small_gemm_form(x, weight, bias, relu):
     form = _GEMM_CHOICE.get(key)
     if form is not None:
         return form
-    forced = os.environ.get("MARL_AMD_SMALL_GEMM", "auto")
+    forced = os.environ.get("MARL_AMD_SMALL_GEMM", "table")
     if forced in ("fused", "plain", "gemv"):
         form = forced if (forced != "gemv" or rows == 1) else "fused"
+    elif forced != "tune":
+        form = _table_form(rows, weight.shape[1], weight.shape[0])
     elif torch.cuda.is_current_stream_capturing():
         return "fused"  # cannot time under capture; decided at the next eager call
     else:

@@ -19,6 +19,10 @@ A recording is an ``.npz`` (or a dict) of one episode over E envs and K steps:
   agents        int [K+1, E, A, 4]  optional: (row, col, dir, holding) with holding 0 none 1 onion 2 plate 3 soup
   pots          int [K+1, E, NP, 2] optional: (onions in the pot, cooking timer)
   items         int [K+1, E, H*W]   optional: what lies on each cell, same codes as holding
+  contested     bool [K, E]         optional: steps on which some agent that wanted to move did not (its
+                                    serving order may have been reconstructed from the outcome)
+
+``tools/record_cogrid_episode.py`` writes this format from the reference's real env.
 
 Whatever optional array is present is compared, exactly.  ``python -m marl_amd.replay file.npz``
 prints the first difference per array (step, env, agent and, for observations, the feature the
@@ -56,21 +60,57 @@ def feature_at(feature: str, num_agents: int, index: int) -> str:
     return f"position {index}"
 
 
-def replay(rec, device=None):
-    """Runs the recording; returns {array name: None | (description of the first difference)}
-    plus the produced arrays under 'produced'."""
+def load_recording(rec):
+    """A recording (path of an .npz, or a dict) with its layout resolved and every array checked
+    against the shapes the format prescribes; needs no GPU.  Returns a dict of numpy arrays plus
+    'rows' (the ASCII grid)."""
     if not isinstance(rec, dict):
         with np.load(rec, allow_pickle=False) as z:
             rec = {k: z[k] for k in z.files}
+    rec = dict(rec)
     rows = [str(r) for r in rec["layout"]] if "layout" in rec else get_layout(str(rec["layout_name"]))
+    if len({len(r) for r in rows}) != 1:
+        raise ValueError("layout rows differ in width")
+    H, W = len(rows), len(rows[0])
+    cells = np.asarray(rec["spawn_cells"])
+    if cells.ndim != 3 or cells.shape[2] != 2:
+        raise ValueError(f"spawn_cells must be [E, A, 2], got {cells.shape}")
+    E, A = cells.shape[:2]
+    actions = np.asarray(rec["actions"])
+    if actions.ndim != 3 or actions.shape[1:] != (E, A):
+        raise ValueError(f"actions must be [K, {E}, {A}], got {actions.shape}")
+    K = actions.shape[0]
+    if K > int(rec["max_steps"]):
+        raise ValueError(f"{K} recorded steps exceed max_steps={int(rec['max_steps'])}: a recording covers one episode")
+    if actions.min(initial=0) < 0 or actions.max(initial=0) > 6:
+        raise ValueError("actions outside 0..6")
+    want = {"spawn_dirs": (E, A), "serve_rank": (K, E, A), "rewards": (K, E, A), "truncated": (K, E, A),
+            "agents": (K + 1, E, A, 4), "items": (K + 1, E, H * W), "contested": (K, E)}
+    for name, shape in want.items():
+        if name in rec and tuple(np.asarray(rec[name]).shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(np.asarray(rec[name]).shape)}")
+    for name, lead in (("obs", (K + 1, E, A)), ("pots", (K + 1, E))):
+        if name in rec and tuple(np.asarray(rec[name]).shape[:len(lead)]) != lead:
+            raise ValueError(f"{name} must start with {lead}, got {tuple(np.asarray(rec[name]).shape)}")
+    if "spawn_dirs" not in rec:
+        raise ValueError("spawn_dirs is missing")
+    if (cells[..., 0] < 0).any() or (cells[..., 0] >= H).any() or (cells[..., 1] < 0).any() or (cells[..., 1] >= W).any():
+        raise ValueError("spawn_cells outside the grid")
+    rec["rows"] = rows
+    return rec
+
+
+def replay(rec, device=None):
+    """Runs the recording; returns {array name: None | (description of the first difference)}
+    plus the produced arrays under 'produced'."""
+    rec = load_recording(rec)
+    rows = rec["rows"]
     feature = str(rec["feature"])
     max_steps = int(rec["max_steps"])
     cells = np.asarray(rec["spawn_cells"])
     E, A = cells.shape[:2]
     actions = np.asarray(rec["actions"])
     K = actions.shape[0]
-    if K > max_steps:
-        raise ValueError(f"{K} recorded steps exceed max_steps={max_steps}: a recording covers one episode")
     W = len(rows[0])
     env = BatchedOvercookedVecEnv(rows, A, feature, E, max_steps=max_steps, device=device, auto_reset=False)
     N, D = env.N, env.D
@@ -126,6 +166,12 @@ def replay(rec, device=None):
             first_desc = f"index {first}"
         report[name] = (f"{len(bad)} entries differ; first: {first_desc}{what}: recorded {want[first]}, "
                         f"produced {got[first]}")
+        if "contested" in rec and len(first) >= 2:
+            # outputs after step k sit at index k + 1 of the [K+1, ...] arrays and at index k of the [K, ...] ones
+            upto = first[0] if got.shape[0] == K + 1 else first[0] + 1
+            seen = bool(np.asarray(rec["contested"])[:upto, first[1]].any())
+            report[name] += ("; a contested step (reconstructed serving order) precedes it in that env" if seen else
+                             "; no contested step precedes it in that env: the rules differ, not the serving order")
     return report
 
 

@@ -165,6 +165,10 @@ def main(argv=None):
         with open(os.path.join(folder, f"{stem}_args_seed_{args.seed}.txt"), "w") as f:
             for k, v in vars(args).items():
                 f.write(f"{k}: {v}\n")
+            from .policy import gemm_choices
+
+            # which library call ran each small policy layer (a fixed function of its shape unless overridden)
+            f.write(f"small_gemm_forms: {sorted(gemm_choices().items())}\n")
         if args.save and args.save_path:
             print("saved", agent.save_model())
     return returns, freq

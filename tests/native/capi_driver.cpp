@@ -62,6 +62,37 @@ static void run_env(const char* const* rows, int height, int A, int feature, int
     EXPECT(marl_env_featurize(env, state, obs, st) == MARL_OK);
     EXPECT(marl_env_export_state(env, state, agents, pots, items, misc, st) == MARL_OK);
     EXPECT(marl_env_import_state(env, state, agents, pots, items, misc, st) == MARL_OK);
+    {
+        // a hostile snapshot: coordinates whose product wraps around int32 into the grid's range,
+        // far-off and negative positions, codes beyond their fields, items on every cell, a huge step
+        // counter.  The library must stay inside its tables (the kernels that follow would fault or
+        // write out of range otherwise) and every agent must come out on a floor cell.
+        std::vector<int32_t> h_agents((size_t)E * A * 4), h_pots((size_t)E * (NP ? NP : 1) * 2), h_misc((size_t)E * 2);
+        std::vector<uint8_t> h_items((size_t)E * HW, 0xFF);
+        const int32_t bad[6][2] = {{65536, 65536}, {0x40000000, 4}, {-1, 3}, {2, -7}, {1 << 30, 1 << 30}, {3, 1 << 20}};
+        for (size_t k = 0; k < (size_t)E * A; ++k) {
+            h_agents[4 * k] = bad[k % 6][0]; h_agents[4 * k + 1] = bad[k % 6][1];
+            h_agents[4 * k + 2] = 0x7FFFFFFF; h_agents[4 * k + 3] = -5;
+        }
+        for (auto& x : h_pots) x = 0x7FFFFFFF;
+        for (size_t e = 0; e < (size_t)E; ++e) { h_misc[2 * e] = 0x7FFFFFF0; h_misc[2 * e + 1] = -1; }
+        HIP_OK(hipMemcpy(agents, h_agents.data(), h_agents.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(pots, h_pots.data(), h_pots.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(items, h_items.data(), h_items.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(misc, h_misc.data(), h_misc.size() * 4, hipMemcpyHostToDevice));
+        EXPECT(marl_env_import_state(env, state, agents, pots, items, misc, st) == MARL_OK);
+        EXPECT(marl_env_featurize(env, state, obs, st) == MARL_OK);
+        EXPECT(marl_env_export_state(env, state, agents, pots, items, misc, st) == MARL_OK);
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpy(h_agents.data(), agents, h_agents.size() * 4, hipMemcpyDeviceToHost));
+        const int W = (int)strlen(rows[0]);
+        for (size_t k = 0; k < (size_t)E * A; ++k) {
+            const int r = h_agents[4 * k], c = h_agents[4 * k + 1];
+            EXPECT(r >= 0 && r < height && c >= 0 && c < W && (rows[r][c] == ' ' || rows[r][c] == '+'));
+            EXPECT(h_agents[4 * k + 2] >= 0 && h_agents[4 * k + 2] < 4 && h_agents[4 * k + 3] >= 0 && h_agents[4 * k + 3] < 4);
+        }
+        EXPECT(marl_env_reset(env, state, obs, nullptr, nullptr, st) == MARL_OK);
+    }
     EXPECT(marl_env_set_auto_reset(env, 0) == MARL_OK);
     EXPECT(marl_env_step(env, state, act, 8, obs, rew, term, trunc, nullptr, st) == MARL_OK);
     EXPECT(marl_env_set_auto_reset(env, 1) == MARL_OK);

@@ -540,3 +540,30 @@ def test_two_host_threads_step_their_own_handles(oracle_mod):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_step_counter_runs_past_16_bits_without_auto_reset(oracle_mod):
+    """A bare env (no restart inside step) that the caller keeps stepping: the step counter is a
+    full word, so `truncated` stays set beyond 65,536 steps instead of wrapping back to 0."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_cramped_room_v0")
+    E, A = 40, 2
+    gpu = BatchedOvercookedVecEnv(rows, A, "global_obs", E, max_steps=1000, seed=2, auto_reset=False)
+    ora = oracle_mod.OracleVecEnv(rows, A, "global_obs", max_steps=1000, num_envs=E, seed=2, auto_reset=False)
+    gpu.reset(); ora.reset()
+    snap = ora.snapshot()
+    snap["misc"][:, 0] = 65530
+    snap["misc"][::2, 0] = 990  # every other env is still inside its episode
+    ora.load_snapshot(snap); gpu.import_state(snap)
+    rng = np.random.default_rng(0)
+    for t in range(14):
+        act = rng.integers(0, 7, size=E * A)
+        o_g, r_g, _, tr_g, _ = gpu.step(torch.from_numpy(act))
+        o_o, r_o, _, tr_o = ora.step(act)
+        np.testing.assert_array_equal(o_g[OBS_KEY].cpu().numpy(), o_o)
+        np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o)
+        late = tr_g.cpu().numpy().reshape(E, A)
+        assert late[1::2].all() and late[::2].all() == (990 + t + 1 >= 1000)
+    _assert_state_equal(gpu, ora)
+    assert gpu.export_state()["misc"][1, 0] == 65530 + 14

@@ -204,8 +204,9 @@ def test_host_array_mode_fresh_arrays_and_staging_reuse():
 
 def test_small_batch_layers_agree_in_both_library_forms(monkeypatch):
     """Below 512 rows a layer runs either as hipBLASLt's fused call or as a rocBLAS product plus
-    in-place bias and ReLU, whichever was faster when the shape was first seen: both forms give
-    the same numbers up to summation order, forward and backward, and the choice is recorded."""
+    in-place bias and ReLU, by a fixed rule on the layer's shape (the same in every run and on every
+    rank): both forms give the same numbers up to summation order, forward and backward, and the
+    form in use is recorded."""
     import marl_amd.policy as pol
     from marl_amd.env import make_env, make_vector_env
 
@@ -233,6 +234,10 @@ def test_small_batch_layers_agree_in_both_library_forms(monkeypatch):
     with torch.no_grad():
         net.get_action_and_value(obs)
     assert all(k[0] == obs.shape[0] for k in pol.gemm_choices()) and len(pol.gemm_choices()) >= 3
+    # without the override the form is a function of the shape alone: the 512-wide hidden layer
+    # through rocBLAS, the others fused
+    assert {k[1:3]: v for k, v in pol.gemm_choices().items()} == {
+        (obs.shape[1], 512): "fused", (512, 256): "plain", (256, 7): "fused", (256, 1): "fused"}
     pol._GEMM_CHOICE.clear()
 
 

@@ -86,3 +86,47 @@ def test_noalloc_rejects_more_rows_than_its_limit():
     t = torch.zeros(4, dtype=torch.int64, device="cuda")
     rc = L.marl_reward_events_noalloc(ctypes.c_void_p(r.data_ptr()), (1 << 24) + 1, 1, ctypes.c_void_p(t.data_ptr()), None, None)
     assert rc == -1 and b"at most" in L.marl_last_error()
+
+
+def test_noalloc_really_allocates_nothing_and_can_be_captured():
+    """What the entry point is for: after a first call on the device (which looks up the static
+    scratch's address) further calls leave the device's free memory untouched, and a call can be
+    captured into a hipGraph and replayed, every replay adding the step's events again."""
+    from marl_amd import _lib
+
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(9)
+    E, A = 70000, 2
+    r = torch.from_numpy(_rewards(rng, E * A)).to(dev)
+    tot = torch.zeros(4, dtype=torch.int64, device=dev)
+    fst = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def call():
+        _lib.check(L.marl_reward_events_noalloc(vp(r.data_ptr()), E, A, vp(tot.data_ptr()), vp(fst.data_ptr()),
+                                                vp(torch.cuda.current_stream(dev).cuda_stream)), "marl_reward_events_noalloc")
+
+    call()  # outside any capture: the one-time address lookup happens here
+    torch.cuda.synchronize()
+    once_t, once_f = tot.clone(), fst.clone()
+    free_before, _ = torch.cuda.mem_get_info(dev)
+    reserved_before = torch.cuda.memory_reserved(dev)
+    for _ in range(50):
+        call()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free_before, "the device's free memory moved across no-allocation calls"
+    assert torch.cuda.memory_reserved(dev) == reserved_before
+    assert torch.equal(tot, once_t * 51)
+
+    tot.zero_(); fst.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call()  # any allocation or other forbidden call in here would invalidate the capture
+    assert int(tot.sum()) == 0  # capture records, it does not run
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tot, once_t * 3)
+    torch.testing.assert_close(fst, once_f * 3, rtol=1e-12, atol=0)
