@@ -282,6 +282,10 @@ FULL_SIZE = [
     ("overcooked_cramped_room_v0", 2, "global_obs", 65536),       # the headline workload
     ("overcooked_counter_circuit_v0", 2, "global_obs", 131072),   # one GPU's share of the 1M-env job
     ("overcooked_coordination_ring_v0", 4, "local_obs", 65536),   # four agents, per-agent observations
+    ("overcooked_forced_coordination_v0", 2, "global_obs", 65536),  # the centralised learner's layout ('+' spawn cells)
+    ("large_overcooked_layout", 4, "global_obs", 32768),          # the reference's own layout, widest rows (D = 420)
+    ("overcooked_coordination_ring_v0", 3, "global_obs", 21848),  # three agents: the quad's fourth lane idles
+    ("overcooked_asymmetric_advantages_v0", 2, "Minimal_spatial_other_agent_aware", 65536),
 ]
 
 
@@ -346,6 +350,37 @@ def test_full_size_every_row_against_oracle(oracle_mod, layout, A, feature, E):
         np.testing.assert_array_equal(te_h[k], te_o)
         np.testing.assert_array_equal(tr_h[k], tr_o)
     assert tr_h.any()
+    _assert_state_equal(gpu, ora)
+
+
+def test_a_million_envs_on_one_gpu_every_row(oracle_mod):
+    """The whole 1,048,576-env counter_circuit job (what eight GPUs share) on a single GPU, every env
+    followed by the oracle: the largest batch the benchmarks name, observation stores in their
+    large-tensor cache policy, an in-kernel restart of every env on the way."""
+    from marl_amd.env import OBS_KEY, BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_counter_circuit_v0")
+    E, A = 1 << 20, 2
+    N = E * A
+    gpu = BatchedOvercookedVecEnv(rows, A, "global_obs", E, max_steps=8, seed=5)
+    ora = oracle_mod.OracleVecEnv(rows, A, "global_obs", max_steps=8, num_envs=E, seed=5, nthreads=_host_threads())
+    host = torch.empty((N, gpu.D), dtype=torch.float32, pin_memory=True)
+    want = torch.empty((N, gpu.D), dtype=torch.float32, device=gpu.device)
+    got = torch.empty_like(want)
+    gpu.reset(out=got)
+    host.numpy()[...] = ora.reset()
+    want.copy_(host)
+    assert torch.equal(got, want)
+    rng = np.random.default_rng(1)
+    for t in range(12):
+        act = _biased_actions(rng, N)
+        _, r_g, _, tr_g, _ = gpu.step(torch.from_numpy(act), out=got)
+        _, r_o, _, tr_o = ora.step(act, out_obs=host.numpy())
+        want.copy_(host)
+        assert torch.equal(got, want), f"observations differ at step {t}"
+        np.testing.assert_array_equal(r_g.cpu().numpy(), r_o)
+        np.testing.assert_array_equal(tr_g.cpu().numpy(), tr_o)
+        assert bool(tr_o.all()) == (t == 7)
     _assert_state_equal(gpu, ora)
 
 
