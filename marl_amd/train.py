@@ -57,14 +57,6 @@ def build_parser():
     p.add_argument("--lam", type=float, default=0.95)
     p.add_argument("--max-steps", type=int, default=1000, help="episode length (overcooked_config.py:108)")
     p.add_argument("--shuffle", choices=["device", "numpy"], default="device")
-    # main.py:148-169: options of the QMIX / SARSA / SAC learners, which are not part of this build;
-    # parsed so that a command line written for the reference is accepted, and otherwise unused
-    for name, typ, default in (("--hidden-dim", int, 256), ("--buffer-size", int, 5000), ("--epsilon-start", float, 1.0),
-                               ("--epsilon-end", float, 0.05), ("--epsilon-decay", float, 0.995),
-                               ("--target-update-freq", int, 200), ("--batch-size-qmix", int, 32),
-                               ("--mixing-embed-dim", int, 32), ("--num-episodes", int, 1000), ("--tau", float, 0.005),
-                               ("--batch-size-sac", int, 32)):
-        p.add_argument(name, type=typ, default=default, help="accepted for compatibility, unused (QMIX / SARSA / SAC only)")
     p.add_argument("--sampler", choices=["fused", "torch"], default="fused",
                    help="rollout action sampling: one HIP launch with a counter RNG, or torch.distributions")
     p.add_argument("--graph-update", choices=["auto", "on", "off"], default="auto",
@@ -78,7 +70,9 @@ def build_parser():
                         "critic and the fused sampler every shard then runs act -> step on its stream and one shard's "
                         "policy GEMMs overlap the other's env kernel (same stored rows as with 1)")
     p.add_argument("--graph-rollout", choices=["auto", "on", "off"], default="auto",
-                   help="replay rollout steps from hipGraphs (auto: at most 16,384 rows per launch)")
+                   help="replay rollout steps from hipGraphs (auto: at most 16,384 rows per launch, on any number of ranks; "
+                        "RCCL collectives between graph replays have run with one rank only so far: if a multi-GPU job "
+                        "stalls, 'off' restores eager rollouts)")
     return p
 
 
