@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "libmarl_amd.so")  # override: diagnostic builds
+# MARL_AMD_LIB: a diagnostic build of this library (profiles/diag/libvar_*.so) instead of the product's;
+# never silent: the load is announced on stderr
+LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "libmarl_amd.so")
 
 EXPORTS = (
     "marl_last_error", "marl_env_create", "marl_env_destroy", "marl_env_set_auto_reset", "marl_env_obs_dim", "marl_env_num_rows",
@@ -36,6 +38,10 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `make -C marl_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    if os.environ.get("MARL_AMD_LIB"):
+        import sys
+
+        print(f"marl_amd: MARL_AMD_LIB is set, loading {LIB_PATH} instead of the product library", file=sys.stderr, flush=True)
     L = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.marl_last_error.restype = ctypes.c_char_p
