@@ -119,6 +119,11 @@ def launch_ranks(n, argv):
     straight through."""
     import subprocess
 
+    # (counting devices does not initialise the GPU)
+    if os.environ.get("MARL_AMD_DIST_BACKEND", "nccl") == "nccl" and n > torch.cuda.device_count():
+        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} GPU(s) are visible: one rank per GPU over RCCL needs {n} "
+              "(MARL_AMD_DIST_BACKEND=gloo lets ranks share a GPU, as a rehearsal of the code path only)", file=sys.stderr)
+        return 2
     return subprocess.run(rank_launch_command(n, argv, free_port())).returncode
 
 

@@ -41,6 +41,7 @@ def test_parent_launches_children_and_touches_no_gpu(monkeypatch):
         raise AssertionError("the launcher process touched the GPU")
 
     monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     for name in ("set_device", "is_available", "current_device", "synchronize", "init"):
         monkeypatch.setattr(torch.cuda, name, boom)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -60,3 +61,21 @@ def test_rank_count_mismatch_is_refused(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     with pytest.raises(SystemExit, match="must agree"):
         bench.main()
+
+
+def test_more_ranks_than_gpus_is_refused_before_anything_starts(monkeypatch, capsys):
+    import subprocess
+
+    import torch
+
+    import bench
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("ranks were started")))
+    monkeypatch.delenv("MARL_AMD_DIST_BACKEND", raising=False)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 2 and "1 GPU(s) are visible" in capsys.readouterr().err

@@ -110,14 +110,20 @@ def test_noalloc_really_allocates_nothing_and_can_be_captured():
     call()  # outside any capture: the one-time address lookup happens here
     torch.cuda.synchronize()
     once_t, once_f = tot.clone(), fst.clone()
-    free_before, _ = torch.cuda.mem_get_info(dev)
     reserved_before = torch.cuda.memory_reserved(dev)
-    for _ in range(50):
-        call()
-    torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info(dev)[0] == free_before, "the device's free memory moved across no-allocation calls"
+    calls, steady = 1, False
+    for _ in range(3):  # the device-wide figure can move for reasons outside this process: one quiet round suffices
+        free_before, _ = torch.cuda.mem_get_info(dev)
+        for _ in range(50):
+            call()
+        calls += 50
+        torch.cuda.synchronize()
+        steady = steady or torch.cuda.mem_get_info(dev)[0] == free_before
+        if steady:
+            break
+    assert steady, "the device's free memory moved across no-allocation calls"
     assert torch.cuda.memory_reserved(dev) == reserved_before
-    assert torch.equal(tot, once_t * 51)
+    assert torch.equal(tot, once_t * calls)
 
     tot.zero_(); fst.zero_()
     torch.cuda.synchronize()
