@@ -88,7 +88,10 @@ size_t marl_env_state_bytes(const marl_env_t *env);/* bytes the caller must allo
 /*
  * vec_env.reset() (agent_environment.py:34,88): every env restarts; d_obs receives
  * float32 [E*A][D] (16-byte aligned).  d_spawn_override / d_dir_override: uint8 [E][A]
- * (cell index row*W+col / direction 0-3) or NULL to draw from the counter RNG.
+ * (cell index row*W+col / direction 0-3) or NULL to draw from the counter RNG.  The caller
+ * names floor cells, a different one per agent of an env; the kernel does not read them back
+ * for checking, it only keeps them inside its tables (a cell that is not floor becomes the
+ * first floor cell, a direction is taken modulo 4).
  * d_state must have been zero-filled before the first reset (the RNG draw counter lives
  * in it and survives resets).
  */

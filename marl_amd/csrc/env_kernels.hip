@@ -270,6 +270,7 @@ __device__ __forceinline__ void reset_env(EnvState<A, NIW>& s, const Lds& T, con
         uint32_t fi;
         if (spawn_ov) {
             fi = aux_g[AUX_FIDX_OF_CELL + spawn_ov[(size_t)e * A + a]];  // overrides name cells
+            fi = fi == 0xFFu ? 0u : fi;  // not a floor cell: the first floor cell, so that every lookup stays inside the tables
         } else {
             const bool use_spawn = P.nspawn > 0;
             const uint32_t n = (use_spawn ? P.nspawn : P.nfloor) - a;
@@ -285,7 +286,7 @@ __device__ __forceinline__ void reset_env(EnvState<A, NIW>& s, const Lds& T, con
             });
         }
         s.f[a] = fi;
-        s.dir[a] = dir_ov ? (uint32_t)dir_ov[(size_t)e * A + a] : s.rng.below(4);
+        s.dir[a] = dir_ov ? ((uint32_t)dir_ov[(size_t)e * A + a] & 3u) : s.rng.below(4);
         s.inv[a] = NONE;
     });
 }

@@ -231,7 +231,25 @@ class BatchedOvercookedVecEnv:
     def _u8(self, x, name):
         if x is None:
             return None
-        t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(self.device, torch.uint8).contiguous()
+        if not torch.is_tensor(x):
+            # host arrays are checked here; a device tensor is taken as it is (no read-back on this
+            # path) and the kernel keeps whatever it names inside its tables
+            a = np.asarray(x)
+            if a.size != self.N:
+                raise ValueError(f"{name} must have {self.E}x{self.A} entries")
+            a = a.reshape(self.E, self.A)
+            if name == "dir_override":
+                if ((a < 0) | (a > 3)).any():
+                    raise ValueError("dir_override holds a direction outside 0..3")
+            elif name == "spawn_override":
+                grid = np.array([list(r) for r in self.layout_rows])
+                floor = np.isin(grid, [" ", "+"]).reshape(-1)
+                if ((a < 0) | (a >= floor.size)).any() or not floor[a].all():
+                    raise ValueError("spawn_override names a cell that is not floor")
+                if self.A > 1 and (np.sort(a, axis=1)[:, 1:] == np.sort(a, axis=1)[:, :-1]).any():
+                    raise ValueError("spawn_override puts two agents on one cell")
+            x = a
+        t = torch.as_tensor(x).to(self.device, torch.uint8).contiguous()
         if t.numel() != self.N:
             raise ValueError(f"{name} must have {self.E}x{self.A} entries")
         return t

@@ -206,6 +206,35 @@ def test_action_dtypes_and_priority_override(oracle_mod, act_dtype):
     assert (gpu.export_state()["misc"][:, 1] == 0).all()
 
 
+def test_reset_overrides_are_checked_on_the_host_and_kept_inside_the_tables_on_the_device():
+    """Host arrays naming a wall, a shared cell or a direction above 3 are refused; the same values
+    handed over as device tensors (not read back) must leave a state every table lookup survives:
+    agents on floor cells, directions 0-3, empty hands."""
+    from marl_amd.env import BatchedOvercookedVecEnv
+
+    rows = get_layout("overcooked_cramped_room_v0")
+    E, A, W = 70, 2, len(rows[0])
+    gpu = BatchedOvercookedVecEnv(rows, A, "global_obs", E, max_steps=50, seed=2)
+    cells = [r * W + c for r, row in enumerate(rows) for c, ch in enumerate(row) if ch in " +"]
+    good = np.tile(np.array([cells[:2]], np.uint8), (E, 1))
+    wall = good.copy(); wall[3, 1] = 0
+    with pytest.raises(ValueError, match="not floor"):
+        gpu.reset(spawn_override=wall)
+    same = good.copy(); same[5] = (cells[0], cells[0])
+    with pytest.raises(ValueError, match="one cell"):
+        gpu.reset(spawn_override=same)
+    with pytest.raises(ValueError, match="outside 0..3"):
+        gpu.reset(dir_override=np.full((E, A), 7, np.uint8))
+    gpu.reset(spawn_override=torch.from_numpy(wall).cuda(), dir_override=torch.full((E, A), 7, dtype=torch.uint8, device="cuda"))
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        gpu.step(torch.from_numpy(rng.integers(0, 7, size=E * A)))
+    snap = gpu.export_state()
+    floor = np.array([[ch in " +" for ch in r] for r in rows])
+    assert floor[snap["agents"][..., 0], snap["agents"][..., 1]].all()
+    assert (snap["agents"][..., 2] <= 3).all() and (snap["agents"][..., 3] <= 3).all()
+
+
 def test_import_state_reproduces_reference_fixture():
     """states/agent_0_dropping_onion_state.npy of the reference, rebuilt by state injection."""
     import os
