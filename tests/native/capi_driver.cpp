@@ -1,6 +1,7 @@
 // The C ABI used from plain C++, no Python and no torch in the process: every entry point of
 // include/marl_amd.h is called for all agent counts, feature sets and a few layouts (odd env
-// counts included), then the argument checks are driven through their failure paths.  Prints one
+// counts included), then the argument checks are driven through their failure paths, and the
+// headline batch is stepped as one handle and as two shards on two streams from one hipGraph.  Prints one
 // line per stage and "capi host pass: ok" at the end.  Built by tests/native/Makefile (run by the
 // GPU suite, tests/test_gpu_capi_native.py) and, with AddressSanitizer on the host code of driver
 // and library, by profiles/diag/capi_host_asan.sh (ASan ends the process at the first host
@@ -93,6 +94,30 @@ static void run_env(const char* const* rows, int height, int A, int feature, int
         }
         EXPECT(marl_env_reset(env, state, obs, nullptr, nullptr, st) == MARL_OK);
     }
+    {
+        // hostile reset overrides (a wall cell, a cell off the grid, directions beyond 3): agents must
+        // still come out on floor cells with a direction in range
+        std::vector<uint8_t> h_spawn((size_t)E * A), h_dir((size_t)E * A);
+        for (size_t k = 0; k < h_spawn.size(); ++k) { h_spawn[k] = (k & 1) ? 0 : 255; h_dir[k] = (uint8_t)(4 + k % 250); }
+        uint8_t* spawn = dalloc<uint8_t>(h_spawn.size());
+        uint8_t* dirs = dalloc<uint8_t>(h_dir.size());
+        HIP_OK(hipMemcpy(spawn, h_spawn.data(), h_spawn.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dirs, h_dir.data(), h_dir.size(), hipMemcpyHostToDevice));
+        EXPECT(marl_env_reset(env, state, obs, spawn, dirs, st) == MARL_OK);
+        EXPECT(marl_env_step(env, state, act, 8, obs, rew, term, trunc, nullptr, st) == MARL_OK);
+        EXPECT(marl_env_export_state(env, state, agents, pots, items, misc, st) == MARL_OK);
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<int32_t> h_agents((size_t)E * A * 4);
+        HIP_OK(hipMemcpy(h_agents.data(), agents, h_agents.size() * 4, hipMemcpyDeviceToHost));
+        const int W = (int)strlen(rows[0]);
+        for (size_t k = 0; k < (size_t)E * A; ++k) {
+            const int r = h_agents[4 * k], c = h_agents[4 * k + 1];
+            EXPECT(r >= 0 && r < height && c >= 0 && c < W && (rows[r][c] == ' ' || rows[r][c] == '+'));
+            EXPECT(h_agents[4 * k + 2] >= 0 && h_agents[4 * k + 2] < 4 && h_agents[4 * k + 3] >= 0 && h_agents[4 * k + 3] < 4);
+        }
+        HIP_OK(hipFree(spawn)); HIP_OK(hipFree(dirs));
+        EXPECT(marl_env_reset(env, state, obs, nullptr, nullptr, st) == MARL_OK);
+    }
     EXPECT(marl_env_set_auto_reset(env, 0) == MARL_OK);
     EXPECT(marl_env_step(env, state, act, 8, obs, rew, term, trunc, nullptr, st) == MARL_OK);
     EXPECT(marl_env_set_auto_reset(env, 1) == MARL_OK);
@@ -117,6 +142,109 @@ static void run_env(const char* const* rows, int height, int A, int feature, int
     for (void* p : {(void*)state, (void*)obs, (void*)rew, (void*)term, (void*)trunc, (void*)act, (void*)prio, (void*)agents,
                     (void*)pots, (void*)items, (void*)misc})
         HIP_OK(hipFree(p));
+}
+
+// The pipelined form from plain C++: the batch as two env handles whose env_index_base continues
+// the numbering, each stepping on a stream of its own, all steps captured into one hipGraph with a
+// branch per shard (fork and join through events, no join between steps).  The two shards must
+// reproduce the single-handle batch bit for bit; the time per step of both forms is printed.
+static void run_pipelined_shards() {
+    const int E = 65536, A = 2, K = 16, half = E / 2;
+    marl_env_t *whole = nullptr, *sh[2] = {nullptr, nullptr};
+    EXPECT(marl_env_create(&whole, CRAMPED, 6, A, MARL_FEAT_GLOBAL_OBS, 1000, E, 9, 0, 0) == MARL_OK);
+    for (int k = 0; k < 2; ++k)
+        EXPECT(marl_env_create(&sh[k], CRAMPED, 6, A, MARL_FEAT_GLOBAL_OBS, 1000, half, 9, (int64_t)k * half, 0) == MARL_OK);
+    const int D = marl_env_obs_dim(whole), N = E * A, Nh = half * A;
+    EXPECT(((size_t)Nh * D) % 4 == 0);
+    std::vector<int64_t> h_act((size_t)K * N);
+    uint32_t x = 12345u;
+    for (auto& a : h_act) { x = x * 1664525u + 1013904223u; a = (int64_t)((x >> 8) % 7u); }
+    int64_t* act = dalloc<int64_t>(h_act.size());
+    HIP_OK(hipMemcpy(act, h_act.data(), h_act.size() * 8, hipMemcpyHostToDevice));
+    // every step's rows are kept (a ring of K + 1 observation tensors per form)
+    float* obs[2]; float* rew[2]; uint8_t *term[2], *trunc[2], *state[2][2];
+    for (int f = 0; f < 2; ++f) {
+        obs[f] = dalloc<float>((size_t)(K + 1) * N * D);
+        rew[f] = dalloc<float>((size_t)K * N);
+        term[f] = dalloc<uint8_t>((size_t)K * N);
+        trunc[f] = dalloc<uint8_t>((size_t)K * N);
+    }
+    state[0][0] = dalloc<uint8_t>(marl_env_state_bytes(whole)); state[0][1] = nullptr;
+    for (int k = 0; k < 2; ++k) state[1][k] = dalloc<uint8_t>(marl_env_state_bytes(sh[k]));
+    hipStream_t main_s, s[2];
+    HIP_OK(hipStreamCreate(&main_s));
+    for (int k = 0; k < 2; ++k) HIP_OK(hipStreamCreate(&s[k]));
+    hipEvent_t fork_ev, join_ev[2], t0, t1;
+    HIP_OK(hipEventCreate(&fork_ev)); HIP_OK(hipEventCreate(&t0)); HIP_OK(hipEventCreate(&t1));
+    for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreate(&join_ev[k]));
+
+    auto whole_steps = [&] {
+        for (int t = 0; t < K; ++t)
+            EXPECT(marl_env_step(whole, state[0][0], act + (size_t)t * N, 8, obs[0] + (size_t)(t + 1) * N * D, rew[0] + (size_t)t * N,
+                                 term[0] + (size_t)t * N, trunc[0] + (size_t)t * N, nullptr, main_s) == MARL_OK);
+    };
+    auto shard_steps = [&] {
+        HIP_OK(hipEventRecord(fork_ev, main_s));
+        for (int k = 0; k < 2; ++k) HIP_OK(hipStreamWaitEvent(s[k], fork_ev, 0));
+        for (int t = 0; t < K; ++t)
+            for (int k = 0; k < 2; ++k) {
+                const size_t r0 = (size_t)t * N + (size_t)k * Nh;  // shard k's rows of step t
+                EXPECT(marl_env_step(sh[k], state[1][k], act + r0, 8, obs[1] + ((size_t)(t + 1) * N + (size_t)k * Nh) * D, rew[1] + r0,
+                                     term[1] + r0, trunc[1] + r0, nullptr, s[k]) == MARL_OK);
+            }
+        for (int k = 0; k < 2; ++k) {
+            HIP_OK(hipEventRecord(join_ev[k], s[k]));
+            HIP_OK(hipStreamWaitEvent(main_s, join_ev[k], 0));
+        }
+    };
+    EXPECT(marl_env_reset(whole, state[0][0], obs[0], nullptr, nullptr, main_s) == MARL_OK);
+    for (int k = 0; k < 2; ++k)
+        EXPECT(marl_env_reset(sh[k], state[1][k], obs[1] + (size_t)k * Nh * D, nullptr, nullptr, main_s) == MARL_OK);
+    whole_steps();
+    shard_steps();
+    HIP_OK(hipStreamSynchronize(main_s));
+    // same rows from both forms: every reward and flag, every observation of every step
+    auto same = [&](const void* a, const void* b, size_t bytes) {
+        std::vector<uint8_t> ha(bytes), hb(bytes);
+        HIP_OK(hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost));
+        return memcmp(ha.data(), hb.data(), bytes) == 0;
+    };
+    EXPECT(same(rew[0], rew[1], (size_t)K * N * 4));
+    EXPECT(same(trunc[0], trunc[1], (size_t)K * N));
+    for (int t = 0; t <= K; ++t) EXPECT(same(obs[0] + (size_t)t * N * D, obs[1] + (size_t)t * N * D, (size_t)N * D * 4));
+
+    // timing: both forms replayed from graphs of K steps
+    hipGraph_t g[2]; hipGraphExec_t ge[2];
+    for (int f = 0; f < 2; ++f) {
+        HIP_OK(hipStreamBeginCapture(main_s, hipStreamCaptureModeThreadLocal));
+        if (f == 0) whole_steps(); else shard_steps();
+        HIP_OK(hipStreamEndCapture(main_s, &g[f]));
+        HIP_OK(hipGraphInstantiate(&ge[f], g[f], nullptr, nullptr, 0));
+    }
+    float us[2];
+    const int reps = 24;
+    for (int f = 0; f < 2; ++f) {
+        for (int r = 0; r < 4; ++r) HIP_OK(hipGraphLaunch(ge[f], main_s));
+        HIP_OK(hipEventRecord(t0, main_s));
+        for (int r = 0; r < reps; ++r) HIP_OK(hipGraphLaunch(ge[f], main_s));
+        HIP_OK(hipEventRecord(t1, main_s));
+        HIP_OK(hipStreamSynchronize(main_s));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, t0, t1));
+        us[f] = ms * 1e3f / (reps * K);
+    }
+    printf("65,536 envs, rows kept, from C++: one handle %.2f us per step, two shards on two streams %.2f us per step (same rows)\n",
+           us[0], us[1]);
+    for (int f = 0; f < 2; ++f) { HIP_OK(hipGraphExecDestroy(ge[f])); HIP_OK(hipGraphDestroy(g[f])); }
+    marl_env_destroy(whole);
+    for (int k = 0; k < 2; ++k) marl_env_destroy(sh[k]);
+    for (int f = 0; f < 2; ++f)
+        for (void* p : {(void*)obs[f], (void*)rew[f], (void*)term[f], (void*)trunc[f]}) HIP_OK(hipFree(p));
+    for (void* p : {(void*)state[0][0], (void*)state[1][0], (void*)state[1][1], (void*)act}) HIP_OK(hipFree(p));
+    HIP_OK(hipEventDestroy(fork_ev)); HIP_OK(hipEventDestroy(t0)); HIP_OK(hipEventDestroy(t1));
+    for (int k = 0; k < 2; ++k) { HIP_OK(hipEventDestroy(join_ev[k])); HIP_OK(hipStreamDestroy(s[k])); }
+    HIP_OK(hipStreamDestroy(main_s));
 }
 
 static void run_small_passes() {
@@ -211,6 +339,7 @@ int main() {
 
     run_small_passes();
     printf("GAE, row sums, reward events, sampling, PPO loss\n");
+    run_pipelined_shards();
     printf("capi host pass: ok\n");
     return 0;
 }

@@ -1,6 +1,7 @@
 """The C ABI from a process without Python or torch: tests/native/capi_driver (plain C++, built by
 `__graft_entry__.build()`) calls every entry point of include/marl_amd.h and the argument checks'
-failure paths."""
+failure paths, then steps the headline batch as one handle and as two shards on two streams from one
+hipGraph (same rows from both)."""
 import os
 import subprocess
 
@@ -16,3 +17,5 @@ def test_every_entry_point_from_plain_cpp():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "capi host pass: ok" in r.stdout
+    assert "two shards on two streams" in r.stdout
+    print(r.stdout)
