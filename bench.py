@@ -262,12 +262,12 @@ def extra_legs(env, actions, store, rew, term, trunc, N, D, B, dev, rank, A, E):
 
     def step_many_leg():
         # the multi-step launch, rows kept
-        if (N * D) % 4 != 0 or R < ring:
+        if (N * D) % 4 != 0:
             return None
         rew_k = torch.empty((ring, N), dtype=torch.float32, device=dev)
         te_k = torch.empty((ring, N), dtype=torch.bool, device=dev)
         tr_k = torch.empty_like(te_k)
-        acts_k = actions[:ring].contiguous()
+        acts_k = actions[torch.arange(ring, device=dev) % R].contiguous()  # one [ring, N] array: the launch prefetches a step ahead
         env.step_many_into(acts_k, store, rew_k, te_k, tr_k)
         reps = 16
         us_m = timed(lambda i: env.step_many_into(acts_k, store, rew_k, te_k, tr_k), reps, dev) / ring
@@ -346,6 +346,11 @@ def main():
                     help="observation tensors the timed steps cycle through (32: every step's rows are kept like in a "
                          "rollout store and drain to HBM; 2: the next step overwrites the rows the consumer has just "
                          "read, they never leave the last-level cache)")
+    ap.add_argument("--action-batches", type=int, default=32,
+                    help="distinct pre-generated action batches the steps cycle through (int64, 8 bytes per row).  32 batches "
+                         "of 131,072 rows are 4 MB per XCD, as much as its L2 holds, so every launch reads its actions from HBM "
+                         "(the default: what a caller with a long pre-generated action sequence sees); 16 or fewer stay in the "
+                         "L2s between uses, as actions a sampler has just written do")
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed env steps for this long before the warm-up steps, so that a short run does not measure "
                          "the GPU's power-saving state (0 = none)")
@@ -395,7 +400,7 @@ def main():
     if (N * D) % 4:
         raise SystemExit(f"--envs {E} with {A} agents and {args.feature}: the rows of one step ({N} x {D} floats) must be a "
                          "multiple of 16 bytes for the tensors of the ring to start aligned; use an env count that is a multiple of 4")
-    R = 32  # distinct pre-generated action batches, cycled
+    R = args.action_batches  # distinct pre-generated action batches, cycled
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     actions = torch.randint(0, 7, (R, N), dtype=torch.int64, device=dev, generator=gen)
     RING = int(max(2, min(args.obs_ring, (8 << 30) // (N * D * 4))))  # at most 8 GB of rows
@@ -444,10 +449,11 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
-    if args.graph and not args.no_graph and args.steps >= R and RING in (2, 4, 8, 16, 32):
+    GL = 32  # steps per graph
+    if args.graph and not args.no_graph and args.steps >= GL and RING in (2, 4, 8, 16, 32):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(R):
+            for i in range(GL):
                 eager(i)
         graph.replay()  # one untimed replay
         torch.cuda.synchronize()
@@ -464,9 +470,9 @@ def main():
     ev0.record()
     done = 0
     if graph is not None:
-        for _ in range(args.steps // R):
+        for _ in range(args.steps // GL):
             graph.replay()
-        done = (args.steps // R) * R
+        done = (args.steps // GL) * GL
     for i in range(done, args.steps):
         eager(i)
     ev1.record()
@@ -541,7 +547,7 @@ def main():
                                    + (f"every step's rows kept (ring of {RING} observation tensors, {RING * N * D * 4 / 1e9:.1f} GB)"
                                       if kept else f"{RING} alternating observation tensors (cache resident)"),
                        "launch": "hipGraph of 32 steps" if graph is not None else "eager",
-                       "obs_ring": RING, "process_group": group, "spinup_ms": args.spinup_ms,
+                       "obs_ring": RING, "action_batches": R, "process_group": group, "spinup_ms": args.spinup_ms,
                        "world_size": dist.get_world_size() if group is not None else 1,
                        "all_reduce_ranks": ranks_seen,
                        "rccl_ranks": ranks_seen if group == "nccl" else None,
