@@ -310,6 +310,14 @@ class BatchedOvercookedVecEnv:
         """Allocation-free step for device-resident loops and graph capture: every argument is
         a preallocated tensor on this env's device (actions int64/int32/uint8 [N]; obs float32
         [N, D]; rewards float32 [N]; terminated/truncated bool or uint8 [N])."""
+        # sizes and element widths only (a few hundred nanoseconds): the kernel writes N rows whatever it is handed
+        N = self.N
+        if (actions.numel() != N or obs.numel() != N * self.D or rewards.numel() != N or terminated.numel() != N
+                or truncated.numel() != N or obs.dtype != torch.float32 or rewards.dtype != torch.float32
+                or terminated.element_size() != 1 or truncated.element_size() != 1
+                or (prio_override is not None and (prio_override.numel() != N or prio_override.element_size() != 1))):
+            raise ValueError(f"step_into wants actions [{N}], obs float32 [{N}, {self.D}], rewards float32 [{N}] and one-byte "
+                             f"terminated / truncated [{N}] (prio_override uint8 [{N}] if given)")
         _lib.check(self._L.marl_env_step(self._h, _ptr(self.state), _ptr(actions), actions.element_size(), _ptr(obs),
                                          _ptr(rewards), _ptr(terminated), _ptr(truncated), _ptr(prio_override),
                                          self._stream()), "marl_env_step")

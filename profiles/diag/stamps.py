@@ -2,6 +2,8 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 from marl_amd.env import BatchedOvercookedVecEnv
 from marl_amd.layouts import get_layout
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _stamped import stamped_step
 E, A = int(os.environ.get("ST_E", 65536)), int(os.environ.get("ST_A", 2))
 env = BatchedOvercookedVecEnv(get_layout(os.environ.get("ST_LAYOUT", "overcooked_cramped_room_v0")), A, os.environ.get("ST_FEAT", "global_obs"), E, seed=1)
 N, D = env.N, env.D
@@ -12,7 +14,7 @@ nw = (E + (64 // (1 if A == 1 else 2 if A == 2 else 4)) - 1) // (64 // (1 if A =
 dbg = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
 acts = torch.randint(0, 7, (8, N), device="cuda")
 for i in range(50):
-    env.step_into(acts[i % 8], obs, rew, term, trunc, prio_override=dbg)
+    stamped_step(env, acts[i % 8], obs, rew, term, trunc, dbg)
 torch.cuda.synchronize()
 full = dbg.cpu().numpy().reshape(nw, 16)
 s = full[:, :8]

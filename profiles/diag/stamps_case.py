@@ -10,7 +10,9 @@ import torch
 
 sys.path.insert(0, os.getcwd())
 from marl_amd.env import BatchedOvercookedVecEnv  # noqa: E402
-from marl_amd.layouts import get_layout  # noqa: E402
+from marl_amd.layouts import get_layout
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _stamped import stamped_step  # noqa: E402
 
 layout, A, feature, E = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 env = BatchedOvercookedVecEnv(get_layout(layout), A, feature, E, seed=1)
@@ -25,7 +27,7 @@ nw = (E * lanes + 63) // 64
 dbg = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
 acts = torch.randint(0, 7, (8, N), device="cuda")
 for i in range(int(os.environ.get("STEPS", "60"))):
-    env.step_into(acts[i % 8], obs[i % 2], rew, term, trunc, prio_override=dbg)
+    stamped_step(env, acts[i % 8], obs[i % 2], rew, term, trunc, dbg)
 torch.cuda.synchronize()
 full = dbg.cpu().numpy().reshape(nw, 16)
 names = ["loads + table staging", "unpack", "step", "rewards + state store", "feature block", "block -> LDS image", "store stream"]
