@@ -187,10 +187,26 @@ def policy_leg(env, store, rew, term, trunc, N, dev, rank, A, world, barrier, re
     run(16, steps)
     barrier()
     wall = reduce_max(time.perf_counter() - t0)
+    env_us = None
+    if shards == 1:
+        # the env launch as it runs inside this loop (a policy forward between two steps), outside the timed
+        # steps: an event on either side of it, median over 64 steps
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for j, (e0, e1) in enumerate(evs):
+            i = 16 + steps + j
+            policy.rollout_step(store[i % ring], logp, val, actions_out=act)
+            e0.record()
+            env.step_into(act, store[(i + 1) % ring], rew, term, trunc)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        env_us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[len(evs) // 2]
     return {
         "metric": "env agent-steps/sec (policy-driven rollout: fp32 MLP forward + sample + fused step+featurize)",
         "value": world * N * steps / wall, "unit": "agent-steps/s", "n_gpus": world, "ms_per_step": wall / steps * 1e3,
-        "steps": steps,
+        "steps": steps, "env_launch_us_in_loop": env_us,
+        "env_launch_us_in_loop_note": None if env_us is None else
+        "event to event around the env launch between two policy forwards, median of 64; compare launch_time_us.median "
+        "(the same measure for back-to-back launches; the events add ~3 us to both)",
         "policy": "obs->512->256->7/1 fp32 MLP (PyTorch-ROCm GEMMs, both heads in one), fused categorical sampling; rows kept; "
                   "every rank its own envs, no collective, slowest rank's wall time"
                   + (f"; the envs of a rank as {shards} shards on streams of their own, each running forward -> sample -> "
