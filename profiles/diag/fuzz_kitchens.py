@@ -1,7 +1,9 @@
 """Differential fuzz of the HIP env against the CPU oracle over random kitchens (one-off evidence run,
 longer and wider than the suite's 24 cases): grids up to 14 x 14, 1-4 agents, every feature set, both
 distance metrics, drawn and caller-given serving orders, short episodes so that envs restart many times.
-Both sides must also agree on which layouts they refuse.
+Both sides must also agree on which layouts they refuse.  Every 25 steps, in half of the cases, a random valid
+state is injected into both (items on any share of the cells, pots in every condition, any holdings): its
+observations are compared at once and play goes on from it.
 
     python profiles/diag/fuzz_kitchens.py [cases] [first seed]
 """
@@ -45,12 +47,39 @@ def random_layout(rng):
     return ["".join(row) for row in grid]
 
 
+def random_snapshot(rng, rows, A, E, NP, max_steps):
+    """a valid state that random play may never reach: items on any share of the floor and counter cells,
+    pots in every condition, any holdings"""
+    H, W = len(rows), len(rows[0])
+    flat = "".join(rows)
+    floor = np.array([k for k, ch in enumerate(flat) if ch in " +"])
+    holder = np.array([k for k, ch in enumerate(flat) if ch in " +C"])
+    agents = np.zeros((E, A, 4), np.int32)
+    items = np.zeros((E, H * W), np.uint8)
+    pots = np.zeros((E, NP, 2), np.int32)
+    misc = np.zeros((E, 2), np.int32)
+    fill = rng.choice([0.0, 0.1, 0.5, 1.0])
+    for e in range(E):
+        cells = rng.choice(floor, size=A, replace=False)
+        agents[e, :, 0], agents[e, :, 1] = cells // W, cells % W
+        agents[e, :, 2] = rng.integers(0, 4, size=A)
+        agents[e, :, 3] = rng.integers(0, 4, size=A)
+        put = holder[rng.random(holder.size) < fill]
+        items[e, put] = rng.integers(1, 4, size=put.size)
+        items[e, cells] = 0
+        for p in range(NP):
+            c = int(rng.integers(0, 4))
+            pots[e, p] = (c, int(rng.integers(0, 31)) if c == 3 else 30)
+        misc[e] = (int(rng.integers(0, max_steps)), int(rng.integers(0, 1 << 20)))
+    return {"agents": agents, "pots": pots, "items": items, "misc": misc}
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     oracle.build()
     dev = torch.device("cuda", 0)
-    ran = refused = capacity = 0
+    ran = refused = capacity = injected = 0
     agent_steps = 0
     t0 = time.perf_counter()
     for case in range(first, first + cases):
@@ -105,13 +134,21 @@ def main():
                         and np.array_equal(snap["items"], ora.items) and np.array_equal(snap["misc"], ora.misc)):
                     print(f"state after step {t} differs:", tag)
                     return 1
+                if rng.random() < 0.5:
+                    snap = random_snapshot(rng, rows, A, E, gpu.NP, max_steps)
+                    gpu.import_state(snap)
+                    ora.load_snapshot(snap)
+                    injected += 1
+                    if not np.array_equal(gpu.featurize().cpu().numpy(), ora.featurize()):
+                        print(f"observations of the state injected after step {t} differ:", tag)
+                        return 1
         agent_steps += E * A * steps
         ran += 1
         gpu.close()
         if (case - first) % 50 == 49:
             print(f"{case - first + 1} cases: {ran} run, {refused} refused by both sides, {agent_steps:.3g} agent-steps identical, "
                   f"{time.perf_counter() - t0:.0f} s", flush=True)
-    print(f"seeds {first}..{first + cases - 1}: {ran} kitchens run, {refused} refused by both sides, {capacity} beyond the library's table sizes, {agent_steps:.3g} agent-steps, "
+    print(f"seeds {first}..{first + cases - 1}: {ran} kitchens run, {refused} refused by both sides, {capacity} beyond the library's table sizes, {injected} random states injected, {agent_steps:.3g} agent-steps, "
           f"every observation, reward and flag of every step and the state every 25 steps: identical ({time.perf_counter() - t0:.0f} s)")
     return 0
 
