@@ -1,3 +1,4 @@
+# Needs a library built with profiles/diag/xcd_split.patch (git apply, then make in marl_amd/csrc): the product does not read these variables.
 # multi-step launch with an uneven split over the XCDs: us per step for several even/odd weights
 for wv in 2 1; do
 for d in 0 0.04 0.06 0.08 0.10 0.12; do
