@@ -22,7 +22,8 @@ What is timed, and what the extra objects in the line mean:
     actions are known up front as they are here), rows kept in the same ring: HBM regime;
   * `two_shards`: the batch as two half-batch env handles on two streams, single-step launches
     replayed from one hipGraph without a join between steps (one shard simulates while the other
-    streams its rows), rows kept: HBM regime;
+    streams its rows), rows kept: HBM regime; `cached_actions` inside it: the same with the actions
+    read from the L2s instead of HBM;
   * `policy_driven`: actions sampled every step from the reference-shaped fp32 MLP (every rank, at
     any N);
   * `peak_measured`: what a plain device fill / copy of the same ring reaches in this run;
@@ -227,22 +228,33 @@ def two_shard_leg(env, actions, store, N, D, B, dev, rank, A, E):
     trunc = torch.empty(N, dtype=torch.bool, device=dev)
     sh.reset(out=store[0])
 
-    def body(k, shard, rows, i):
-        shard.step_into(actions[i % actions.shape[0]][rows], store[(i + 1) % ring][rows], rew[rows], term[rows], trunc[rows])
+    def measure(batches):
+        def body(k, shard, rows, i):
+            shard.step_into(actions[i % batches][rows], store[(i + 1) % ring][rows], rew[rows], term[rows], trunc[rows])
 
-    sh.run_pipelined(range(ring), body)
-    torch.cuda.synchronize(dev)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
         sh.run_pipelined(range(ring), body)
-    g.replay()
-    reps = 16
-    us = timed(lambda i: g.replay(), reps, dev) / ring
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sh.run_pipelined(range(ring), body)
+        g.replay()
+        reps = 16
+        return timed(lambda i: g.replay(), reps, dev) / ring
+
+    R = actions.shape[0]
+    us = measure(R)
+    # the same with at most 8 action batches in rotation: they stay in the XCD L2s between uses, as actions a
+    # sampler has just written do, instead of being fetched from HBM behind the other shard's row stream
+    us_cached = measure(min(R, 8))
     return {"regime": f"marl_amd.sharded_env.ShardedVecEnv, two shards of {E // 2} envs on two streams, single-step launches, "
                       f"run_pipelined over {ring} steps captured into one hipGraph (a branch per shard, no join between "
                       "steps); every step's rows kept: HBM",
             "bound": "hbm", "us_per_step": us, "value": N / us * 1e6, "achieved": N * B / us / 1e3, "unit": "GB/s",
-            "frac": N * B / us / 1e3 / HBM_PEAK_GBS}
+            "frac": N * B / us / 1e3 / HBM_PEAK_GBS,
+            "cached_actions": {"action_batches": min(R, 8), "us_per_step": us_cached, "value": N / us_cached * 1e6,
+                               "frac": N * B / us_cached / 1e3 / HBM_PEAK_GBS,
+                               "what": "the same graph with the steps' actions read from the L2s (few batches in rotation) "
+                                       "instead of HBM: what a per-shard sampler's actions cost to read"}}
 
 
 def guarded(out, name, fn):
