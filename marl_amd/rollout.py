@@ -50,7 +50,8 @@ def aligned_runs(first, count):
 
 class ScalarLog:
     """Stand-in for tensorboard's SummaryWriter when tensorboard is not installed: keeps
-    scalars in memory (``.scalars[tag] = [(step, value), ...]``)."""
+    scalars in memory (``.scalars[tag] = [(step, value), ...]``) and, when it has a ``log_dir``,
+    writes them to ``<log_dir>/scalars.csv`` (tag, step, value) on ``close()``."""
 
     def __init__(self, log_dir=None):
         self.log_dir = log_dir
@@ -60,7 +61,18 @@ class ScalarLog:
         self.scalars.setdefault(tag, []).append((int(step), float(value)))
 
     def close(self):
-        pass
+        if not self.log_dir or not self.scalars:
+            return
+        import csv
+        import os
+
+        os.makedirs(self.log_dir, exist_ok=True)
+        with open(os.path.join(self.log_dir, "scalars.csv"), "w", newline="") as f:
+            out = csv.writer(f)
+            out.writerow(["tag", "step", "value"])
+            for tag in sorted(self.scalars):
+                for step, value in self.scalars[tag]:
+                    out.writerow([tag, step, repr(value)])
 
 
 def make_writer(log_dir):

@@ -142,6 +142,8 @@ def main(argv=None):
                                            writer=writer, progress=(rank == 0 and sys.stderr.isatty()))
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if writer is not None:
+        writer.close()  # tensorboard: flush the event file; without tensorboard: <log_dir>/scalars.csv
     if rank == 0:
         steps = num_updates * batch_size * world
         print(f"{steps} agent-steps in {dt:.1f} s ({steps / max(dt, 1e-9):.3e}/s), {len(returns)} episodes; "

@@ -44,3 +44,21 @@ def test_a_failing_bench_leg_reports_its_error_and_spares_the_line(capsys):
     assert out["good"] == {"value": 2.0} and "skipped" not in out
     assert out["bad"]["error"].startswith("ZeroDivisionError") and out["value"] == 1.0
     assert "ZeroDivisionError" in capsys.readouterr().err  # the traceback still goes to stderr
+
+
+def test_scalar_log_keeps_scalars_and_writes_them_on_close(tmp_path):
+    """Without tensorboard the metrics of agent_environment.py:90-94 / agents/MAPPO.py:211-218 still reach the disk."""
+    import csv
+
+    from marl_amd.rollout import ScalarLog
+
+    log = ScalarLog(str(tmp_path / "runs" / "x"))
+    log.add_scalar("episode_rewards", 1.5, 0)
+    log.add_scalar("episode_rewards", 2.25, 1)
+    log.add_scalar("losses/value_loss", 0.1, 7)
+    assert log.scalars["episode_rewards"] == [(0, 1.5), (1, 2.25)]
+    log.close()
+    rows = list(csv.reader(open(tmp_path / "runs" / "x" / "scalars.csv")))
+    assert rows[0] == ["tag", "step", "value"]
+    assert rows[1:] == [["episode_rewards", "0", "1.5"], ["episode_rewards", "1", "2.25"], ["losses/value_loss", "7", "0.1"]]
+    ScalarLog(None).close()  # nothing to write, nowhere to write it: no error
